@@ -1,0 +1,115 @@
+/*
+ * pyglm_hip.h -- C ABI of libpyglm_hip.so, the MI355X (gfx950) Gibbs hot path of slinderman/pyglm.
+ *
+ * The reference is pure Python; its native boundary on this path is (a) the third-party `pypolyagamma`
+ * sampler and (b) BLAS/LAPACK reached through NumPy/SciPy.  Each entry point below names the reference
+ * call site(s) it replaces (paths relative to /root/reference).  Conventions:
+ *   - every pointer is a DEVICE pointer unless marked host; the caller owns every buffer, the library borrows it
+ *     for the call only and allocates nothing persistent;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it;
+ *   - return value 0 = ok, non-zero = error, message from pgl_last_error() (host, thread-local);
+ *   - no hidden RNG state: stochastic entries take (seed, stream-id, element) counters (see oracle/pg_oracle.c
+ *     header for the stream specification);
+ *   - matrices are row-major fp64 with explicit leading dimensions (in elements).  "k-major" means the
+ *     contraction index is the row index.  Leading dimensions and readable column counts must be even and base
+ *     pointers 16-byte aligned for operands of the MFMA contraction.
+ */
+#ifndef PYGLM_HIP_H
+#define PYGLM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGL_ABI_VERSION 1
+
+int pgl_abi_version(void);
+const char* pgl_last_error(void);
+
+/* ---- random stream -------------------------------------------------------------------------------------------- */
+/* out[4*i..4*i+3] = Philox4x32-10(counter = (j | purpose<<24, elem0+i, stream lo, stream hi), key = seed). Test hook. */
+int pgl_philox_words(uint64_t seed, uint32_t purpose, uint32_t j, uint64_t elem0, uint64_t stream, uint32_t* out, size_t n, void* hip_stream);
+
+/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; b must be integer valued).
+ * Replaces pypolyagamma.pgdrawvpar(ppgs, n, z, out) at pyglm/regression.py:504-507 (samplers built at :474-477). */
+int pgl_pg_draw(const double* b, const double* z, double* out, size_t len, uint64_t seed, uint64_t stream, uint64_t elem0, void* hip_stream);
+
+/* ---- design matrix -------------------------------------------------------------------------------------------- */
+/* X[t][n*B+b] = sum_l basis[l][b] * S[t-1-l][n], clipped at 0 if clip; X[t][N*B] = 1 (bias regressor); optional
+ * transposed copy Xt[d][t].  Replaces convolve_with_basis, pyglm/utils/basis.py:5-34 (called from models.py:74-75). */
+int pgl_design_matrix(const double* S, long lds, const double* basis, double* X, long ldx, double* Xt, long ldxt, int T, int N, int B, int R,
+                      int clip, void* hip_stream);
+/* dst[c][r] = src[r][c] */
+int pgl_transpose(const double* src, long ld_src, double* dst, long ld_dst, int rows, int cols, void* hip_stream);
+
+/* ---- activation, PG draw, log-likelihood ---------------------------------------------------------------------- */
+/* Psi[t][n] = sum_d Xt[d][t] * Wt[d][n] for nloc neurons at once (Xt: K x T k-major with K = Dk rows, Wt: K x nloc).
+ * Replaces the per-neuron dgemv X.dot(W) at pyglm/regression.py:195-201 (bias is added by pgl_pg_loglik). Dk % 16 == 0. */
+int pgl_activation(const double* Xt, long ldxt, const double* Wt, long ldw, double* Psi, long ldpsi, int T, int Dk, int nloc, void* hip_stream);
+
+/* In one pass over Psi (T x nloc): psi += bias; kappa = a(y) - b(y)/2 (regression.py:510-511); omega ~ PG(b(y), psi)
+ * (:496-508) on stream (neuron0+n, sweep), element elem0+t; ll_out[n] (+)= sum_t log c + a psi - b log1p(exp psi) (:491-494).
+ * obs 0 = Bernoulli (:514-522), 1 = negative binomial a=y, b=y+xi. Omega/Kappa may be NULL (log-likelihood only).
+ * llpart: scratch of pgl_pg_loglik_partials(T) * nloc doubles. */
+int pgl_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, double* Omega, long ldo, double* Kappa, long ldk,
+                  double* llpart, double* ll_out, int accumulate, int T, int nloc, int obs, double xi, uint64_t seed, uint64_t sweep,
+                  uint64_t neuron0, uint64_t elem0, void* hip_stream);
+int pgl_pg_loglik_partials(int T);
+
+/* ---- likelihood statistics ------------------------------------------------------------------------------------ */
+/* J[z][i][j] (+)= sum_t W[t][z] * X[t][i] * X[t][j], i >= j tiles only (lower triangle valid), z in [0, nz), i,j in [0, D).
+ * Replaces XO = X*omega[:,None]; J += XO.T.dot(X) at pyglm/regression.py:251-252 without the T x D temporary.
+ * X: Tp x ldx (Tp % 16 == 0, rows >= T zero); W: Tp x ldw weights (rows >= T zero). */
+int pgl_weighted_gram(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ,
+                      int accumulate, void* hip_stream);
+/* C[r][c] (+)= sum_t A[t][r] * X[t][c]  (plain k-major contraction; the border sums X'omega, sum omega, X'kappa, sum kappa of
+ * pyglm/regression.py:253-260 with A = [Omega | Kappa] and X carrying the ones column). */
+int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long ldb, int b_cols, double* C, long ldc, int M, int N, int K,
+                    double alpha, double beta, void* hip_stream);
+/* J_post = J_lkhd + J_prior, h_post = h_lkhd + h_prior in the (D+2)-square layout [J, bias row D, potential row D+1].
+ * Replaces _prior_sufficient_statistics + the additions at pyglm/regression.py:210-223, 253-260, 270-271.
+ * border: 2*nloc_b rows (omega sums then kappa sums) x ldb; Jw [nb][N][B][B], hw [nb][N][B], Jb [nb], hb [nb]. */
+int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* border_omega, const double* border_kappa, long ldb, const double* Jw,
+                           const double* hw, const double* Jb, const double* hb, int nb, int N, int B, void* hip_stream);
+
+/* ---- collapsed adjacency resampling (pyglm/regression.py:282-320 + 343-378) ------------------------------------ */
+typedef struct {
+    double* M; long ldj; long strideM;   /* sweep tableau per neuron, (D+2)^2, lower triangle; starts as a copy of J_post */
+    int nb, N, B;
+    const int* perm;                     /* [nb][N] proposal order (npr.permutation at :286) */
+    const double* u;                     /* [nb][N] uniform of proposal step k (sample_discrete_from_log at :315) */
+    const double* rho;                   /* [nb][N] */
+    const double* c0;                    /* [nb][N] prior term of block m: 1/2 log|J_w| - 1/2 mu_w' J_w mu_w */
+    int* a;                              /* [nb][N] in/out */
+    const int* skip;                     /* [nb] or NULL: 1 = deterministic sparsity (regression.py:153-155, 274-275): no proposals */
+    int* d_idx; double* d_sign; int* d_cnt;   /* [nb][kmax], [nb][kmax], [nb]: pivot list of the pending tableau update */
+    int* batch_k;                        /* [nb] scratch */
+    double* G;                           /* [nb][kmax][kmax] scratch */
+    double* Ut; double* Wt; long ldu;    /* [nb][kmax][ldu] scratch, ldu >= D+2, even */
+    int* status;                         /* [nb] sticky flags: 1 non-PD block, 2 singular pivot, 4 non-PD posterior */
+} pgl_flip_t;
+int pgl_flip_kmax(void);                         /* pivots (scalar rows) per tableau update */
+int pgl_flip_window_blocks(int B);               /* blocks proposed per window */
+int pgl_flip_apply(const pgl_flip_t* s, void* hip_stream);              /* sweep the tableau on the listed pivots */
+int pgl_flip_decide(const pgl_flip_t* s, int window, void* hip_stream); /* run one window of proposals; fills the pivot list */
+
+/* ---- weight conditional (pyglm/regression.py:323-340) ---------------------------------------------------------- */
+typedef struct {
+    const double* J; long ldj; long strideJ;   /* assembled posterior */
+    const int* a;                              /* [nb][N] */
+    int* act; long ldact; int* na;             /* [nb][ldact] scratch (ldact >= D+1), [nb] active sizes (out) */
+    double* Ac; long ldc; long strideC;        /* [nb][ldc][ldc] scratch */
+    double* hc;                                /* [2][nb][ldc] scratch */
+    const double* z; long ldz;                 /* [nb][ldz] standard normals; the first na[n] are consumed (randn at sample_gaussian) */
+    double* W; double* b;                      /* out: [nb][N*B] (zeros where a = 0), [nb] */
+    int nb, N, B;
+    int* status;
+} pgl_chol_t;
+int pgl_active_index(const pgl_chol_t* s, void* hip_stream);                  /* fills act / na */
+int pgl_sample_weights(const pgl_chol_t* s, int na_max, void* hip_stream);    /* na_max >= max_n na[n] (read back by the caller) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

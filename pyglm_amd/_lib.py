@@ -1,0 +1,83 @@
+"""ctypes binding of libpyglm_hip.so (C ABI: include/pyglm_hip.h). Fails loudly when the library is absent."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpyglm_hip.so")
+
+c_p, c_l, c_i, c_d, c_u64, c_u32, c_sz = (ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_uint64, ctypes.c_uint32, ctypes.c_size_t)
+
+
+class FlipState(ctypes.Structure):   # pgl_flip_t
+    _fields_ = [("M", c_p), ("ldj", c_l), ("strideM", c_l), ("nb", c_i), ("N", c_i), ("B", c_i),
+                ("perm", c_p), ("u", c_p), ("rho", c_p), ("c0", c_p), ("a", c_p), ("skip", c_p),
+                ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("G", c_p),
+                ("Ut", c_p), ("Wt", c_p), ("ldu", c_l), ("status", c_p)]
+
+
+class CholState(ctypes.Structure):   # pgl_chol_t
+    _fields_ = [("J", c_p), ("ldj", c_l), ("strideJ", c_l), ("a", c_p), ("act", c_p), ("ldact", c_l), ("na", c_p),
+                ("Ac", c_p), ("ldc", c_l), ("strideC", c_l), ("hc", c_p), ("z", c_p), ("ldz", c_l),
+                ("W", c_p), ("b", c_p), ("nb", c_i), ("N", c_i), ("B", c_i), ("status", c_p)]
+
+
+# symbol -> argument types; every function returns int status unless noted. Mirrors include/pyglm_hip.h 1:1.
+SIGNATURES = {
+    "pgl_abi_version": [],
+    "pgl_last_error": [],
+    "pgl_philox_words": [c_u64, c_u32, c_u32, c_u64, c_u64, c_p, c_sz, c_p],
+    "pgl_pg_draw": [c_p, c_p, c_p, c_sz, c_u64, c_u64, c_u64, c_p],
+    "pgl_design_matrix": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_p],
+    "pgl_transpose": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "pgl_activation": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "pgl_pg_loglik": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_u64, c_u64, c_u64, c_u64, c_p],
+    "pgl_pg_loglik_partials": [c_i],
+    "pgl_weighted_gram": [c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_p],
+    "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
+    "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "pgl_flip_kmax": [],
+    "pgl_flip_window_blocks": [c_i],
+    "pgl_flip_apply": [ctypes.POINTER(FlipState), c_p],
+    "pgl_flip_decide": [ctypes.POINTER(FlipState), c_i, c_p],
+    "pgl_active_index": [ctypes.POINTER(CholState), c_p],
+    "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
+}
+
+_lib = None
+
+
+class PglError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once). No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PglError("libpyglm_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C pyglm_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the export is missing
+        fn.argtypes = args
+        fn.restype = ctypes.c_char_p if name == "pgl_last_error" else ctypes.c_int
+    if lib.pgl_abi_version() != 1:
+        raise PglError("libpyglm_hip.so ABI version %d != 1" % lib.pgl_abi_version())
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise PglError("%s failed (%d): %s" % (name, rc, lib.pgl_last_error().decode()))
+    return rc
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

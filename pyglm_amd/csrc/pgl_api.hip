@@ -1,0 +1,156 @@
+// extern "C" entry points of libpyglm_hip.so (declared and documented in include/pyglm_hip.h).
+#include "pgl_common.h"
+#include "../../include/pyglm_hip.h"
+#include <cstdarg>
+#include <cstdio>
+
+static thread_local char g_err[512] = "";
+void pgl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// kernels' host launchers (other translation units)
+int pgl_k_philox_words(uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint32_t*, size_t, hipStream_t);
+int pgl_k_pg_draw(const double*, const double*, double*, size_t, uint64_t, uint64_t, uint64_t, hipStream_t);
+int pgl_k_pg_loglik(double*, long, const double*, const double*, long, double*, long, double*, long, double*, double*, int, int, int, int, double,
+                    uint64_t, uint64_t, uint64_t, uint64_t, hipStream_t);
+int pgl_k_pg_loglik_nblk(int);
+int pgl_k_basis_conv(const double*, long, const double*, double*, long, double*, long, int, int, int, int, int, hipStream_t);
+int pgl_k_transpose(const double*, long, double*, long, int, int, hipStream_t);
+int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const double*, const double*, int,
+                        int, int, hipStream_t);
+struct PglFlipState {
+    double* M; long ldj; long strideM; int nb, N, B;
+    const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
+    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Ut; double* Wt; long ldu; int* status;
+};
+int pgl_k_flip_apply(const PglFlipState&, hipStream_t);
+int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);
+int pgl_k_flip_kmax(void);
+int pgl_k_flip_window_blocks(int);
+struct PglCholState {
+    const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
+    double* Ac; long ldc; long strideC; double* hc; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
+};
+int pgl_k_chol_index(const PglCholState&, hipStream_t);
+int pgl_k_chol_sample(const PglCholState&, int, hipStream_t);
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int pgl_abi_version(void) { return PGL_ABI_VERSION; }
+const char* pgl_last_error(void) { return g_err; }
+
+int pgl_philox_words(uint64_t seed, uint32_t purpose, uint32_t j, uint64_t elem0, uint64_t stream, uint32_t* out, size_t n, void* st) {
+    PGL_CHECK_ARG(out != nullptr || n == 0);
+    return pgl_k_philox_words(seed, purpose, j, elem0, stream, out, n, ST(st));
+}
+
+int pgl_pg_draw(const double* b, const double* z, double* out, size_t len, uint64_t seed, uint64_t stream, uint64_t elem0, void* st) {
+    PGL_CHECK_ARG((z != nullptr && out != nullptr) || len == 0);
+    return pgl_k_pg_draw(b, z, out, len, seed, stream, elem0, ST(st));
+}
+
+int pgl_design_matrix(const double* S, long lds, const double* basis, double* X, long ldx, double* Xt, long ldxt, int T, int N, int B, int R,
+                      int clip, void* st) {
+    PGL_CHECK_ARG(S && basis && X && T > 0 && N > 0 && B > 0 && R > 0);
+    PGL_CHECK_ARG(ldx >= (long)N * B + 1 && lds >= N && (Xt == nullptr || ldxt >= T));
+    return pgl_k_basis_conv(S, lds, basis, X, ldx, Xt, ldxt, T, N, B, R, clip, ST(st));
+}
+
+int pgl_transpose(const double* src, long ld_src, double* dst, long ld_dst, int rows, int cols, void* st) {
+    PGL_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows);
+    return pgl_k_transpose(src, ld_src, dst, ld_dst, rows, cols, ST(st));
+}
+
+int pgl_activation(const double* Xt, long ldxt, const double* Wt, long ldw, double* Psi, long ldpsi, int T, int Dk, int nloc, void* st) {
+    PGL_CHECK_ARG(Xt && Wt && Psi && T > 0 && nloc > 0 && Dk > 0 && Dk % 16 == 0);
+    PGL_CHECK_ARG(ldxt >= T && ldw >= nloc && ldpsi >= nloc);
+    PglGemmArgs a{};
+    a.A = Xt; a.lda = ldxt; a.strideA = 0;
+    a.B = Wt; a.ldb = ldw; a.strideB = 0;
+    a.C = Psi; a.ldc = ldpsi; a.strideC = 0;
+    a.M = T; a.N = nloc; a.K = Dk;
+    a.a_cols = (int)(ldxt & ~1L); a.b_cols = (int)(ldw & ~1L);
+    a.nbatch = 1; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
+    return pgl_launch_gemm(PGL_GEMM_PLAIN, a, ST(st));
+}
+
+int pgl_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, double* Omega, long ldo, double* Kappa, long ldk,
+                  double* llpart, double* ll_out, int accumulate, int T, int nloc, int obs, double xi, uint64_t seed, uint64_t sweep,
+                  uint64_t neuron0, uint64_t elem0, void* st) {
+    PGL_CHECK_ARG(Psi && Y && llpart && ll_out && T > 0 && nloc > 0 && (obs == 0 || obs == 1));
+    PGL_CHECK_ARG(obs == 0 || (xi > 0 && xi == (double)(long)xi));
+    return pgl_k_pg_loglik(Psi, ldpsi, bias, Y, ldy, Omega, ldo, Kappa, ldk, llpart, ll_out, accumulate, T, nloc, obs, xi, seed, sweep, neuron0,
+                           elem0, ST(st));
+}
+int pgl_pg_loglik_partials(int T) { return pgl_k_pg_loglik_nblk(T); }
+
+int pgl_weighted_gram(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ,
+                      int accumulate, void* st) {
+    PGL_CHECK_ARG(X && W && J && Tp > 0 && Tp % 16 == 0 && D > 0 && nz > 0 && ldj >= D && ldw >= nz && x_cols <= ldx);
+    PglGemmArgs a{};
+    a.A = X; a.lda = ldx; a.strideA = 0;
+    a.B = X; a.ldb = ldx; a.strideB = 0;
+    a.C = J; a.ldc = ldj; a.strideC = strideJ;
+    a.W = W; a.ldw = ldw;
+    a.M = D; a.N = D; a.K = Tp;
+    a.a_cols = x_cols & ~1; a.b_cols = x_cols & ~1;
+    a.nbatch = (nz + 1) / 2; a.nz_total = nz;
+    a.alpha = 1.0; a.beta = accumulate ? 1.0 : 0.0; a.tri = 1;
+    return pgl_launch_gemm(PGL_GEMM_GRAM2, a, ST(st));
+}
+
+int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long ldb, int b_cols, double* C, long ldc, int M, int N, int K,
+                    double alpha, double beta, void* st) {
+    PGL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % 16 == 0 && ldc >= N);
+    PglGemmArgs a{};
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.a_cols = a_cols & ~1; a.b_cols = b_cols & ~1;
+    a.nbatch = 1; a.alpha = alpha; a.beta = beta; a.tri = 0;
+    return pgl_launch_gemm(PGL_GEMM_PLAIN, a, ST(st));
+}
+
+int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* border_omega, const double* border_kappa, long ldb, const double* Jw,
+                           const double* hw, const double* Jb, const double* hb, int nb, int N, int B, void* st) {
+    PGL_CHECK_ARG(J && border_omega && border_kappa && Jw && hw && Jb && hb && nb > 0 && N > 0 && B > 0);
+    PGL_CHECK_ARG(ldj >= (long)N * B + 2 && ldb >= (long)N * B + 1);
+    return pgl_k_assemble_post(J, ldj, strideJ, border_omega, border_kappa, ldb, Jw, hw, Jb, hb, nb, N, B, ST(st));
+}
+
+static PglFlipState to_state(const pgl_flip_t* s) {
+    return PglFlipState{s->M, s->ldj, s->strideM, s->nb, s->N, s->B, s->perm, s->u, s->rho, s->c0, s->a, s->skip,
+                        s->d_idx, s->d_sign, s->d_cnt, s->batch_k, s->G, s->Ut, s->Wt, s->ldu, s->status};
+}
+int pgl_flip_kmax(void) { return pgl_k_flip_kmax(); }
+int pgl_flip_window_blocks(int B) { return pgl_k_flip_window_blocks(B); }
+int pgl_flip_apply(const pgl_flip_t* s, void* st) {
+    PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Ut && s->Wt && s->status);
+    PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0);
+    return pgl_k_flip_apply(to_state(s), ST(st));
+}
+int pgl_flip_decide(const pgl_flip_t* s, int window, void* st) {
+    PGL_CHECK_ARG(s && s->M && s->perm && s->u && s->rho && s->c0 && s->a && s->d_idx && s->d_sign && s->d_cnt && s->status);
+    PGL_CHECK_ARG(s->B >= 1 && s->B <= 32 && window >= 0);
+    return pgl_k_flip_decide(to_state(s), window, ST(st));
+}
+
+static PglCholState to_cstate(const pgl_chol_t* s) {
+    return PglCholState{s->J, s->ldj, s->strideJ, s->a, s->act, s->ldact, s->na, s->Ac, s->ldc, s->strideC, s->hc, s->z, s->ldz,
+                        s->W, s->b, s->nb, s->N, s->B, s->status};
+}
+int pgl_active_index(const pgl_chol_t* s, void* st) {
+    PGL_CHECK_ARG(s && s->a && s->act && s->na && s->nb > 0 && s->ldact >= (long)s->N * s->B + 1);
+    return pgl_k_chol_index(to_cstate(s), ST(st));
+}
+int pgl_sample_weights(const pgl_chol_t* s, int na_max, void* st) {
+    PGL_CHECK_ARG(s && s->J && s->act && s->na && s->Ac && s->hc && s->z && s->W && s->b && s->status);
+    PGL_CHECK_ARG(na_max >= 1 && na_max <= s->N * s->B + 1 && s->ldc >= na_max + 1 && s->ldc % 2 == 0 && s->ldz >= na_max);
+    return pgl_k_chol_sample(to_cstate(s), na_max, ST(st));
+}
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+// Gaussian conditional of the active weights for a batch of neurons (gfx950).
+//
+// Reference: pyglm/regression.py:323-340 (_resample_W): Jp = J_post[ix_(a,a)], hp = h_post[a],
+// [W_active; b] = sample_gaussian(J=Jp, h=hp)  ==  L = chol(Jp);  x = L^-T z + Jp^-1 hp   (pybasicbayes, published form).
+// Steps here: (1) compact the active sub-block (both triangles) into Ac; (2) blocked right-looking Cholesky in the
+// UPPER form Ac = U'U (U = L'), so every panel U[q0:q0+64, :] is k-major and feeds the fp64 MFMA rank-64 update of the
+// trailing matrix directly (pgl_gemm.hip, upper-triangular tiles); (3) U'w = h, U mu = w, U x = z;  out = mu + x.
+#include "pgl_common.h"
+
+namespace {
+
+constexpr int NBC = 64;
+
+struct CholArgs {
+    const double* J; long ldj; long strideJ;   // assembled posterior (lower triangle valid), M = D+2, h in row D+1
+    const int* a;                              // [nb][N]
+    int* act; long ldact;                      // [nb][ldact] active scalar rows (ascending blocks, bias last)
+    int* na;                                   // [nb]
+    double* Ac; long ldc; long strideC;        // [nb][ldc][ldc] compact active block -> U in place (upper)
+    double* hc;                                // [nb][ldc]  h_active -> w -> mu
+    const double* z; long ldz;                 // [nb][ldz]
+    double* W;                                 // [nb][N*B] out
+    double* b;                                 // [nb] out
+    int N, B;
+    int* status;
+};
+
+__global__ __launch_bounds__(256) void active_index_kernel(CholArgs g) {
+    const int n = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int cnt = 0;
+    int* act = g.act + (long)n * g.ldact;
+    for (int m = 0; m < g.N; ++m)
+        if (g.a[(long)n * g.N + m])
+            for (int b = 0; b < g.B; ++b) act[cnt++] = m * g.B + b;
+    act[cnt++] = g.N * g.B;
+    g.na[n] = cnt;
+}
+
+__global__ __launch_bounds__(256) void gather_active_kernel(CholArgs g) {
+    const int n = blockIdx.z;
+    const int na = g.na[n];
+    const int i = blockIdx.y;                       // compact row
+    const int j = blockIdx.x * 256 + threadIdx.x;   // compact col
+    if (i >= na || j >= na) return;
+    const int* act = g.act + (long)n * g.ldact;
+    const int gi = act[i], gj = act[j];
+    const double* J = g.J + (long)n * g.strideJ;
+    g.Ac[(long)n * g.strideC + (long)i * g.ldc + j] = gi >= gj ? J[(long)gi * g.ldj + gj] : J[(long)gj * g.ldj + gi];
+    if (j == 0) g.hc[(long)n * g.ldc + i] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
+}
+
+// factor the 64x64 diagonal block at q0: A11 = U11' U11, U11 written to the upper triangle in place
+__global__ __launch_bounds__(256) void potrf_diag_kernel(CholArgs g, int q0) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int na = g.na[n];
+    if (q0 >= na) return;
+    const int nb = min(NBC, na - q0);
+    __shared__ double A[NBC][NBC + 1];
+    __shared__ int s_bad;
+    double* Ag = g.Ac + (long)n * g.strideC + (long)q0 * g.ldc + q0;
+    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; A[i][j] = Ag[(long)(i <= j ? i : j) * g.ldc + (i <= j ? j : i)]; }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    // right-looking lower Cholesky on the symmetric block (L = U11'), column by column
+    for (int p = 0; p < nb; ++p) {
+        if (tid == 0) { double d = A[p][p]; if (!(d > 0.0)) { s_bad = 1; d = 1.0; } A[p][p] = sqrt(d); }
+        __syncthreads();
+        const double dinv = 1.0 / A[p][p];
+        for (int i = p + 1 + tid; i < nb; i += 256) A[i][p] *= dinv;
+        __syncthreads();
+        const int rem = nb - p - 1;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int i = p + 1 + e / rem, j = p + 1 + e % rem;
+            if (j <= i) A[i][j] -= A[i][p] * A[j][p];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (i <= j) Ag[(long)i * g.ldc + j] = A[j][i]; }
+    if (tid == 0 && s_bad) atomicOr(&g.status[n], 4);
+}
+
+// row panel: U12 = U11^-T A12 ; one thread per trailing column
+__global__ __launch_bounds__(256) void trsm_panel_kernel(CholArgs g, int q0) {
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int na = g.na[n];
+    if (q0 + NBC >= na) return;
+    __shared__ double U[NBC][NBC + 1];
+    double* Ab = g.Ac + (long)n * g.strideC;
+    for (int e = tid; e < NBC * NBC; e += 256) { const int i = e / NBC, j = e % NBC; U[i][j] = (i <= j) ? Ab[(long)(q0 + i) * g.ldc + q0 + j] : 0.0; }
+    __syncthreads();
+    const int c = q0 + NBC + blockIdx.x * 256 + tid;
+    if (c >= na) return;
+    double x[NBC];
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) x[i] = Ab[(long)(q0 + i) * g.ldc + c];
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) {
+        double s = x[i];
+#pragma unroll
+        for (int j = 0; j < NBC; ++j)
+            if (j < i) s -= U[j][i] * x[j];
+        x[i] = s / U[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) Ab[(long)(q0 + i) * g.ldc + c] = x[i];
+}
+
+// one workgroup per neuron:  U'w = h (forward, axpy form), U mu = w and U x = z (backward, dot form); scatter mu + x
+__global__ __launch_bounds__(256) void solve_sample_kernel(CholArgs g) {
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = g.na[n];
+    const double* U = g.Ac + (long)n * g.strideC;
+    double* h = g.hc + (long)n * g.ldc;            // becomes w, then mu
+    double* xz = h + (long)gridDim.x * g.ldc;      // second plane of hc: z -> x
+    const double* z = g.z + (long)n * g.ldz;
+    __shared__ double red[4];
+    for (int i = tid; i < na; i += 256) xz[i] = z[i];
+    __syncthreads();
+    // forward: for each row j: w_j = h_j / U_jj; h[j+1:] -= U[j][j+1:] * w_j
+    for (int j = 0; j < na; ++j) {
+        const double wj = h[j] / U[(long)j * g.ldc + j];
+        __syncthreads();
+        if (tid == 0) h[j] = wj;
+        for (int c = j + 1 + tid; c < na; c += 256) h[c] -= U[(long)j * g.ldc + c] * wj;
+        __syncthreads();
+    }
+    // backward (two right-hand sides at once)
+    for (int i = na - 1; i >= 0; --i) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = i + 1 + tid; c < na; c += 256) { const double uic = U[(long)i * g.ldc + c]; s1 += uic * h[c]; s2 += uic * xz[c]; }
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+        __shared__ double r1[4], r2[4];
+        if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            const double d = U[(long)i * g.ldc + i];
+            h[i] = (h[i] - ((r1[0] + r1[1]) + (r1[2] + r1[3]))) / d;
+            xz[i] = (xz[i] - ((r2[0] + r2[1]) + (r2[2] + r2[3]))) / d;
+        }
+        __syncthreads();
+    }
+    (void)red;
+    // scatter: zeros for inactive blocks
+    const int D = g.N * g.B;
+    double* W = g.W + (long)n * D;
+    for (int i = tid; i < D; i += 256) W[i] = 0.0;
+    __syncthreads();
+    const int* act = g.act + (long)n * g.ldact;
+    for (int i = tid; i < na; i += 256) {
+        const double v = h[i] + xz[i];
+        if (i == na - 1) g.b[n] = v; else W[act[i]] = v;
+    }
+}
+
+}  // namespace
+
+struct PglCholState {
+    const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
+    double* Ac; long ldc; long strideC; double* hc; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
+};
+
+static CholArgs mk(const PglCholState& s) {
+    return CholArgs{s.J, s.ldj, s.strideJ, s.a, s.act, s.ldact, s.na, s.Ac, s.ldc, s.strideC, s.hc, s.z, s.ldz, s.W, s.b, s.N, s.B, s.status};
+}
+
+int pgl_k_chol_index(const PglCholState& s, hipStream_t st) {
+    hipLaunchKernelGGL(active_index_kernel, dim3(s.nb), dim3(64), 0, st, mk(s));
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+// na_max: host-side upper bound of the active sizes (read back from s.na by the caller)
+int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
+    CholArgs g = mk(s);
+    if (na_max <= 0) return PGL_OK;
+    hipLaunchKernelGGL(gather_active_kernel, dim3((na_max + 255) / 256, na_max, s.nb), dim3(256), 0, st, g);
+    PGL_CHECK_LAUNCH();
+    for (int q0 = 0; q0 < na_max; q0 += NBC) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0);
+        PGL_CHECK_LAUNCH();
+        const int rem = na_max - q0 - NBC;
+        if (rem <= 0) break;
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + 255) / 256, s.nb), dim3(256), 0, st, g, q0);
+        PGL_CHECK_LAUNCH();
+        PglGemmArgs t{};
+        const double* P = s.Ac + (long)q0 * s.ldc + (q0 + NBC);   // U12: [64][rem], k-major
+        t.A = P; t.lda = s.ldc; t.strideA = s.strideC;
+        t.B = P; t.ldb = s.ldc; t.strideB = s.strideC;
+        t.C = s.Ac + (long)(q0 + NBC) * s.ldc + (q0 + NBC); t.ldc = s.ldc; t.strideC = s.strideC;
+        t.M = rem; t.N = rem; t.K = NBC; t.a_cols = rem + (rem & 1); t.b_cols = t.a_cols; t.nbatch = s.nb; t.nz_total = 0;
+        t.alpha = -1.0; t.beta = 1.0; t.tri = 2; t.batch_k = nullptr; t.batch_dim = s.na; t.dim_off = q0 + NBC; t.W = nullptr; t.ldw = 0;
+        int rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(solve_sample_kernel, dim3(s.nb), dim3(256), 0, st, g);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}

@@ -1,0 +1,48 @@
+// Shared declarations for the libpyglm_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define PGL_OK 0
+#define PGL_ERR_ARG 1
+#define PGL_ERR_HIP 2
+
+void pgl_set_error(const char* fmt, ...);
+
+#define PGL_CHECK_ARG(cond)                                                              \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            pgl_set_error("%s:%d: argument check failed: %s", __FILE__, __LINE__, #cond); \
+            return PGL_ERR_ARG;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define PGL_CHECK_LAUNCH()                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess) {                                                                    \
+            pgl_set_error("%s:%d: kernel launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return PGL_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---- fp64 MFMA "TN" contraction (pgl_gemm.hip):  C[m][n] = beta*C + alpha * sum_k w[k] * A[k][m] * B[k][n]
+struct PglGemmArgs {
+    const double* A; long lda; long strideA;   // A is K x M, row-major (k-major); rows padded to K%16==0
+    const double* B; long ldb; long strideB;   // B is K x N, row-major
+    double* C; long ldc; long strideC;         // C is M x N, row-major
+    const double* W; long ldw;                 // weighted mode: W[k][z_global], z_global = batch*WZ + z
+    int M, N, K;
+    int a_cols, b_cols;                        // readable columns of A / B rows (even); loads beyond give 0
+    int nbatch;                                // batches (weighted mode: groups of WZ weight columns)
+    int nz_total;                              // weighted mode: number of valid weight columns / outputs
+    double alpha, beta;
+    int tri;                                   // 0: all tiles; 1: tiles tm >= tn (lower); 2: tiles tm <= tn (upper)
+    const int* batch_k;                        // optional per-batch K (multiple of 16; 0 = skip batch)
+    const int* batch_dim; int dim_off;         // optional per-batch square size: M = N = max(0, batch_dim[b] - dim_off)
+};
+enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
+int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);

@@ -1,0 +1,338 @@
+// Collapsed spike-and-slab resampling of the adjacency indicators a[m] for a batch of neurons (gfx950).
+//
+// Reference: pyglm/regression.py:282-320 (_collapsed_resample_a) + :343-378 (_marginal_likelihood): for every
+// presynaptic m in a random order the reference extracts the active sub-block of (J_prior, J_post), takes two
+// dense Choleskys and two dpotrs -- O((sum(a) B)^3) per proposal, N+1 times per neuron.
+//
+// Here the same log-odds come from a symmetric SWEEP TABLEAU of the posterior system, kept per neuron:
+//     A = [[J_post, h_post], [h_post', 0]]   (size D+2, lower triangle stored),   M = sweep(A, S)
+// where S = {bias} U {active blocks}.  With P = J_SS^-1:
+//     inactive m:  M_mm = Schur complement  Sigma_m = J_mm - J_mS P J_Sm,   M_mh = r_m = h_m - J_mS P h_S
+//     active   m:  M_mm = -P_mm,                                            M_mh = mu_m = (P h_S)_m
+// so the change in log marginal likelihood for switching block m on is
+//     -1/2 log|Sigma_m| + 1/2 r' Sigma^-1 r + c0[m]      (inactive)      [c0 = prior term, 1/2 log|J_w| - 1/2 mu_w' J_w mu_w]
+//     +1/2 log|P_mm|    + 1/2 mu' P_mm^-1 mu + c0[m]     (active)
+// -- O(B^3) per proposal.  Because J_prior is block diagonal (regression.py:218) its Cholesky terms reduce to c0.
+// A proposal window of R blocks only ever touches the (R B + 1)^2 sub-tableau on those blocks and h, so a window is
+// gathered into LDS, its R proposals run there (accepted flips = local block sweeps), and the NET set Delta of changed
+// blocks is applied to the full tableau as one symmetric rank-|Delta|B update:
+//     G = (M_DD)^-1;   M_RR -= M_RD G M_DR;   M_RD = M_RD G Sg;   M_DD = -Sg G Sg      (Sg = diag(+1 forward, -1 reverse))
+// (the non-pivot formula is the same for forward and reverse sweeps; derivation in DESIGN.md).  The rank-k update
+// runs on the fp64 MFMA kernel (pgl_gemm.hip, lower-triangular tiles only).
+#include "pgl_common.h"
+
+namespace {
+
+constexpr int KMAX = 128;   // max pivots (scalar rows) per tableau update
+constexpr int KWIN = 96;    // max scalar rows of blocks in one proposal window
+
+struct FlipArgs {
+    double* M; long ldj; long strideM;           // tableau per neuron
+    int N, B, R;                                 // R = blocks per window
+    const int* perm;                             // [nb][N]
+    const double* u;                             // [nb][N]
+    const double* rho;                           // [nb][N]
+    const double* c0;                            // [nb][N]
+    int* a;                                      // [nb][N] in/out
+    const int* skip;                             // [nb] or null
+    int* d_idx;                                  // [nb][KMAX] scalar row index of each pivot
+    double* d_sign;                              // [nb][KMAX]
+    int* d_cnt;                                  // [nb]
+    int* batch_k;                                // [nb]  padded K for the MFMA update (0 = nothing to do)
+    double* G;                                   // [nb][KMAX][KMAX]
+    double* Ut; double* Wt; long ldu;            // [nb][KMAX][ldu]
+    int* status;                                 // [nb] sticky error flags (1 = non-PD block met)
+};
+
+__device__ __forceinline__ double tab_get(const double* M, long ld, int i, int j) { return i >= j ? M[(long)i * ld + j] : M[(long)j * ld + i]; }
+
+// ------------------------------------------------------------------ proposals of one window, in LDS
+__global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int N = g.N, B = g.B, D = N * B;
+    const int k0 = window * g.R;
+    const int nblk = min(g.R, N - k0);
+    if (nblk <= 0 || (g.skip && g.skip[n])) { if (tid == 0) g.d_cnt[n] = 0; return; }
+    const int nl = nblk * B + 1, ldl = nl + 1;
+    double* L = lds;                         // [nl][ldl]
+    double* Tm = L + (size_t)nl * ldl;       // [nl][B]
+    double* Cinv = Tm + (size_t)nl * B;      // [B][B]
+    double* Cb = Cinv + B * B;               // [B][B] cholesky scratch
+    double* vb = Cb + B * B;                 // [B]
+    __shared__ int s_flip, s_sign;
+    __shared__ int s_flipped[KWIN];
+
+    const double* M = g.M + (long)n * g.strideM;
+    const int* perm = g.perm + (long)n * N;
+    for (int e = tid; e < nl * nl; e += 256) {
+        const int i = e / nl, j = e % nl;
+        const int gi = (i < nl - 1) ? perm[k0 + i / B] * B + i % B : D + 1;
+        const int gj = (j < nl - 1) ? perm[k0 + j / B] * B + j % B : D + 1;
+        L[i * ldl + j] = tab_get(M, g.ldj, gi, gj);
+    }
+    __syncthreads();
+
+    const int hcol = nl - 1;
+    for (int k = 0; k < nblk; ++k) {
+        const int m = perm[k0 + k], p0 = k * B;
+        if (tid == 0) {
+            const int am = g.a[(long)n * N + m];
+            const double sgn = am ? -1.0 : 1.0;
+            bool ok = true;
+            double logdet = 0.0;
+            for (int i = 0; i < B; ++i) {        // Cholesky of Q = sgn * L[p,p] (lower, in Cb)
+                for (int j = 0; j <= i; ++j) {
+                    double s = sgn * L[(p0 + i) * ldl + p0 + j];
+                    for (int x = 0; x < j; ++x) s -= Cb[i * B + x] * Cb[j * B + x];
+                    if (i == j) { if (!(s > 0.0)) { ok = false; s = 1.0; } Cb[i * B + i] = sqrt(s); logdet += log(s); }
+                    else Cb[i * B + j] = s / Cb[j * B + j];
+                }
+            }
+            double quad = 0.0;
+            for (int i = 0; i < B; ++i) {        // y = Lc^-1 v ;  quad = y'y = v' Q^-1 v
+                double s = L[(p0 + i) * ldl + hcol];
+                for (int x = 0; x < i; ++x) s -= Cb[i * B + x] * vb[x];
+                vb[i] = s / Cb[i * B + i];
+                quad += vb[i] * vb[i];
+            }
+            if (!ok) atomicOr(&g.status[n], 1);
+            const double dml = (am ? 0.5 * logdet : -0.5 * logdet) + 0.5 * quad + g.c0[(long)n * N + m];
+            const double rho = g.rho[(long)n * N + m];
+            int v;
+            if (rho == 0.0 || rho == 1.0) {
+                v = 0;   // reference :298/:307: 0*log(0) = NaN reaches sample_discrete_from_log, which then returns 0
+            } else {
+                const double d = dml + log(rho) - log(1.0 - rho);       // lps[1] - lps[0]
+                const double mx = d > 0.0 ? d : 0.0;
+                const double e0 = exp(-mx), e1 = exp(d - mx);           // exp(lps - max)
+                const double uu = g.u[(long)n * N + k0 + k];
+                v = (uu * (e0 + e1) > e0) ? 1 : 0;                      // cum = [e0, e0+e1]; count(r > cum)
+            }
+            s_flip = (v != am);
+            s_sign = v ? 1 : -1;                 // forward sweep when switching on
+            s_flipped[k] = (v != am) ? (v ? 1 : -1) : 0;
+            g.a[(long)n * N + m] = v;
+        }
+        __syncthreads();
+        const int do_flip = s_flip, flip_sign = s_sign;   // block-uniform; re-read only after the barrier below
+        __syncthreads();
+        if (do_flip) {
+            // Cinv = (L[p,p])^-1 = sgn * Q^-1, column x solved by thread x from the Cholesky factor
+            if (tid < B) {
+                const int x = tid;
+                double col[32];
+                for (int i = 0; i < B; ++i) {            // forward Lc y = e_x
+                    double s = (i == x) ? 1.0 : 0.0;
+                    for (int j = 0; j < i; ++j) s -= Cb[i * B + j] * col[j];
+                    col[i] = s / Cb[i * B + i];
+                }
+                for (int i = B - 1; i >= 0; --i) {       // backward Lc' z = y
+                    double s = col[i];
+                    for (int j = i + 1; j < B; ++j) s -= Cb[j * B + i] * col[j];
+                    col[i] = s / Cb[i * B + i];
+                }
+                const double sg = (flip_sign > 0) ? 1.0 : -1.0;   // forward: block was inactive -> L[p,p] = +Q
+                for (int i = 0; i < B; ++i) Cinv[i * B + x] = sg * col[i];
+            }
+            __syncthreads();
+            for (int e = tid; e < nl * B; e += 256) {    // Tm = L[:,p] Cinv
+                const int i = e / B, x = e % B;
+                double s = 0.0;
+                for (int y = 0; y < B; ++y) s += L[i * ldl + p0 + y] * Cinv[y * B + x];
+                Tm[e] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < nl * nl; e += 256) {   // non-pivot entries
+                const int i = e / nl, j = e % nl;
+                if ((i >= p0 && i < p0 + B) || (j >= p0 && j < p0 + B)) continue;
+                double s = 0.0;
+                for (int x = 0; x < B; ++x) s += Tm[i * B + x] * L[(p0 + x) * ldl + j];
+                L[i * ldl + j] -= s;
+            }
+            __syncthreads();
+            const double sg = (flip_sign > 0) ? 1.0 : -1.0;
+            for (int e = tid; e < nl * B; e += 256) {    // pivot rows / columns
+                const int i = e / B, x = e % B;
+                if (i >= p0 && i < p0 + B) { L[i * ldl + p0 + x] = -Cinv[(i - p0) * B + x]; }
+                else { const double val = sg * Tm[e]; L[i * ldl + p0 + x] = val; L[(p0 + x) * ldl + i] = val; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        int cnt = 0;
+        for (int k = 0; k < nblk; ++k)
+            if (s_flipped[k]) {
+                const int m = perm[k0 + k];
+                for (int b = 0; b < B; ++b) { g.d_idx[(long)n * KMAX + cnt] = m * B + b; g.d_sign[(long)n * KMAX + cnt] = (double)s_flipped[k]; ++cnt; }
+            }
+        g.d_cnt[n] = cnt;
+    }
+}
+
+// ------------------------------------------------------------------ G = (M_DD)^-1 by in-order symmetric sweeps (every pivot block is definite)
+__global__ __launch_bounds__(256) void invert_kernel(FlipArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int k = g.d_cnt[n];
+    double* Gn = g.G + (long)n * KMAX * KMAX;
+    if (k <= 0) { if (tid == 0) g.batch_k[n] = 0; return; }
+    const int ld = k + 1;
+    double* A = lds;                 // [k][ld]
+    double* colp = A + (size_t)k * ld;   // [k]
+    const double* M = g.M + (long)n * g.strideM;
+    const int* idx = g.d_idx + (long)n * KMAX;
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        A[i * ld + j] = tab_get(M, g.ldj, idx[i], idx[j]);
+    }
+    __syncthreads();
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    for (int p = 0; p < k; ++p) {
+        for (int i = tid; i < k; i += 256) colp[i] = A[i * ld + p];
+        __syncthreads();
+        const double d = colp[p];
+        if (tid == 0 && !(fabs(d) > 0.0)) s_bad = 1;
+        const double inv = 1.0 / d;
+        for (int e = tid; e < k * k; e += 256) {
+            const int i = e / k, j = e % k;
+            double v;
+            if (i == p && j == p) v = -inv;
+            else if (i == p) v = colp[j] * inv;
+            else if (j == p) v = colp[i] * inv;
+            else v = A[i * ld + j] - colp[i] * colp[j] * inv;
+            A[i * ld + j] = v;
+        }
+        __syncthreads();
+    }
+    // all-forward sweep of the whole block gives -A^-1
+    for (int e = tid; e < KMAX * KMAX; e += 256) {
+        const int i = e / KMAX, j = e % KMAX;
+        Gn[e] = (i < k && j < k) ? -A[i * ld + j] : 0.0;
+    }
+    if (tid == 0) { g.batch_k[n] = (k + 15) & ~15; if (s_bad) atomicOr(&g.status[n], 2); }
+}
+
+// ------------------------------------------------------------------ Ut[q][c] = M[idx[q], c]  (old panel, k-major), zero rows up to the padded K
+__global__ __launch_bounds__(256) void gather_panel_kernel(FlipArgs g) {
+    const int n = blockIdx.y;
+    const int k = g.d_cnt[n];
+    if (k <= 0) return;
+    const int kp = (k + 15) & ~15;
+    const int Md = g.N * g.B + 2;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.ldu) return;
+    const double* M = g.M + (long)n * g.strideM;
+    const int* idx = g.d_idx + (long)n * KMAX;
+    double* Ut = g.Ut + (long)n * KMAX * g.ldu;
+    for (int q = 0; q < kp; ++q) {
+        double v = 0.0;
+        if (q < k && c < Md) v = tab_get(M, g.ldj, idx[q], c);
+        Ut[(long)q * g.ldu + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------ pivot rows/columns after the rank-k update
+__global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
+    const int n = blockIdx.y;
+    const int k = g.d_cnt[n];
+    if (k <= 0) return;
+    __shared__ int s_idx[KMAX];
+    __shared__ double s_sg[KMAX];
+    __shared__ short s_piv[256];   // position in idx of column c, or -1
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int Md = g.N * g.B + 2;
+    for (int q = threadIdx.x; q < k; q += 256) { s_idx[q] = g.d_idx[(long)n * KMAX + q]; s_sg[q] = g.d_sign[(long)n * KMAX + q]; }
+    s_piv[threadIdx.x] = -1;
+    __syncthreads();
+    for (int q = threadIdx.x; q < k; q += 256) {
+        const int cc = s_idx[q] - blockIdx.x * 256;
+        if (cc >= 0 && cc < 256) s_piv[cc] = (short)q;
+    }
+    __syncthreads();
+    if (c >= Md) return;
+    double* M = g.M + (long)n * g.strideM;
+    const double* Wt = g.Wt + (long)n * KMAX * g.ldu;
+    const double* Gn = g.G + (long)n * KMAX * KMAX;
+    const int r = s_piv[threadIdx.x];
+    for (int q = 0; q < k; ++q) {
+        const int gq = s_idx[q];
+        double v;
+        if (r < 0) v = s_sg[q] * Wt[(long)q * g.ldu + c];
+        else { if (gq < c) continue; v = -s_sg[q] * Gn[q * KMAX + r] * s_sg[r]; }
+        if (gq >= c) M[(long)gq * g.ldj + c] = v; else M[(long)c * g.ldj + gq] = v;
+    }
+}
+
+}  // namespace
+
+size_t pgl_k_flip_lds_decide(int B, int R) {
+    const int nl = R * B + 1;
+    return ((size_t)nl * (nl + 1) + (size_t)nl * B + 2 * (size_t)B * B + B) * sizeof(double);
+}
+
+static int set_lds(const void* fn, size_t bytes) {
+    if (bytes > 160 * 1024) { pgl_set_error("LDS request %zu > 160 KiB", bytes); return PGL_ERR_ARG; }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGL_ERR_HIP; }
+    return PGL_OK;
+}
+
+struct PglFlipState {
+    double* M; long ldj; long strideM; int nb, N, B;
+    const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
+    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Ut; double* Wt; long ldu; int* status;
+};
+
+int pgl_k_flip_window_blocks(int B) { int r = KWIN / B; return r < 1 ? 0 : r; }
+
+// apply the pivot list currently in (d_idx, d_sign, d_cnt) to every neuron's tableau
+int pgl_k_flip_apply(const PglFlipState& s, hipStream_t st) {
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, pgl_k_flip_window_blocks(s.B), s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Ut, s.Wt, s.ldu, s.status};
+    const size_t lds_inv = ((size_t)KMAX * (KMAX + 1) + KMAX) * sizeof(double);
+    static bool once = false;
+    if (!once) { int rc = set_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv); if (rc) return rc; once = true; }
+    const int Md = s.N * s.B + 2;
+    hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);
+    PGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu + 255) / 256), s.nb), dim3(256), 0, st, g);
+    PGL_CHECK_LAUNCH();
+    // Wt = G Ut   (K x ldu), then  M -= Wt' Ut  on lower-triangular tiles
+    PglGemmArgs w{};
+    w.A = s.G; w.lda = KMAX; w.strideA = (long)KMAX * KMAX;
+    w.B = s.Ut; w.ldb = s.ldu; w.strideB = (long)KMAX * s.ldu;
+    w.C = s.Wt; w.ldc = s.ldu; w.strideC = (long)KMAX * s.ldu;
+    w.M = KMAX; w.N = (int)s.ldu; w.K = KMAX; w.a_cols = KMAX; w.b_cols = (int)s.ldu; w.nbatch = s.nb; w.nz_total = 0;
+    w.alpha = 1.0; w.beta = 0.0; w.tri = 0; w.batch_k = s.batch_k; w.batch_dim = nullptr; w.dim_off = 0; w.W = nullptr; w.ldw = 0;
+    int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st);
+    if (rc) return rc;
+    PglGemmArgs t{};
+    t.A = s.Wt; t.lda = s.ldu; t.strideA = (long)KMAX * s.ldu;
+    t.B = s.Ut; t.ldb = s.ldu; t.strideB = (long)KMAX * s.ldu;
+    t.C = s.M; t.ldc = s.ldj; t.strideC = s.strideM;
+    t.M = Md; t.N = Md; t.K = KMAX; t.a_cols = (int)s.ldu; t.b_cols = (int)s.ldu; t.nbatch = s.nb; t.nz_total = 0;
+    t.alpha = -1.0; t.beta = 1.0; t.tri = 1; t.batch_k = s.batch_k; t.batch_dim = nullptr; t.dim_off = 0; t.W = nullptr; t.ldw = 0;
+    rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fixup_kernel, dim3((Md + 255) / 256, s.nb), dim3(256), 0, st, g);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
+    const int R = pgl_k_flip_window_blocks(s.B);
+    if (R < 1) { pgl_set_error("B=%d exceeds the window capacity %d", s.B, KWIN); return PGL_ERR_ARG; }
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Ut, s.Wt, s.ldu, s.status};
+    const size_t lds = pgl_k_flip_lds_decide(s.B, R);
+    static size_t lds_set = 0;
+    if (lds > lds_set) { int rc = set_lds(reinterpret_cast<const void*>(decide_kernel), lds); if (rc) return rc; lds_set = lds; }
+    hipLaunchKernelGGL(decide_kernel, dim3(s.nb), dim3(256), lds, st, g, window);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_flip_kmax(void) { return KMAX; }

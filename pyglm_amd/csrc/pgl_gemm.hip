@@ -1,0 +1,216 @@
+// fp64 MFMA contraction for gfx950:  C[m][n] = beta*C + alpha * sum_k w_z[k] * A[k][m] * B[k][n]
+//
+// This one template is the omega-weighted Gram  J_n = X' diag(omega_n) X  (reference
+// pyglm/regression.py:251-252, `XO = X*omega[:,None]; XO.T.dot(X)` -- here the T x D temporary is never
+// formed: omega scales the A fragment in registers), the batched activation Psi = X W' (:195-201), the
+// border sums X'omega, X'kappa (:253-260) and the symmetric rank-k updates of the flip tableau / Cholesky.
+//
+// Mapping to CDNA4 (measured, tools/ubench2_f64.hip): v_mfma_f64_16x16x4_f64 issues once per 64 cycles per
+// SIMD (78.6 TFLOP/s chip peak at 2.4 GHz) from a single wave with a single accumulator; f64 VALU shares
+// that pipe, so the only f64 VALU in the loop is the 4 weight multiplies per 16 MFMAs.
+//   * both operands are k-major ("TN"): a wave reads an A or B fragment as lanes (l&15) -> 16 consecutive
+//     doubles of row k0+(l>>4); LDS row stride = tile width + 16 doubles (== 16 mod 32) makes every
+//     ds_read_b64 conflict-free and the global->LDS copy fully coalesced (1 KiB per wave-instruction).
+//   * wave tile 64x64 (16 accumulators, 128 VGPRs); workgroup = WM x WN x WZ waves.  WZ = 2 puts two
+//     neurons (two weight columns) on the same staged X tiles: 32 flop per byte staged.
+//   * LDS double buffer, register-staged prefetch of tile k+1 behind the MFMAs of tile k, one barrier per tile.
+//   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the 32
+//     workgroups resident on one XCD share the same X panels through that XCD's L2.
+#include "pgl_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int PAD = 16;
+
+template <int WM, int WN, int WZ, bool WEIGHTED>
+struct Cfg {
+    static constexpr int BM = WM * 64, BN = WN * 64;
+    static constexpr int SA = BM + PAD, SB = BN + PAD;
+    static constexpr int THREADS = WM * WN * WZ * 64;
+    static constexpr int A_ELEMS = BK * SA, B_ELEMS = BK * SB, W_ELEMS = WEIGHTED ? BK * WZ : 0;
+    static constexpr int STAGE = A_ELEMS + B_ELEMS + W_ELEMS;
+    static constexpr size_t LDS_BYTES = 2ull * STAGE * sizeof(double);
+    // 16-byte loads per thread per K-tile
+    static constexpr int A_LD = (BK * BM / 2) / THREADS, B_LD = (BK * BN / 2) / THREADS;
+    static_assert((BK * BM / 2) % THREADS == 0 && (BK * BN / 2) % THREADS == 0, "tile/threads mismatch");
+};
+
+__device__ __forceinline__ int isqrt_tri(int t) {
+    // largest r with r(r+1)/2 <= t
+    int r = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long)(r + 1) * (r + 2) / 2 <= t) ++r;
+    while ((long)r * (r + 1) / 2 > t) --r;
+    return r;
+}
+
+template <int WM, int WN, int WZ, bool WEIGHTED>
+__global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g) {
+    using C = Cfg<WM, WN, WZ, WEIGHTED>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+
+    // ---- work decode (XCD-aware: consecutive slots on one XCD walk the batch / M-tile index)
+    const int ntm = (g.M + C::BM - 1) / C::BM, ntn = (g.N + C::BN - 1) / C::BN;
+    const int ntiles = g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn;
+    const long total = (long)ntiles * g.nbatch;
+    const long chunk = (total + 7) / 8;
+    const long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
+    int tile, batch, tm, tn;
+    if (g.nbatch > 1) { tile = (int)(w / g.nbatch); batch = (int)(w % g.nbatch); }
+    else { tile = (int)w; batch = 0; }
+    if (g.tri) { tm = isqrt_tri(tile); tn = tile - tm * (tm + 1) / 2; if (g.tri == 2) { const int s_ = tm; tm = tn; tn = s_; } }
+    else { tm = tile % ntm; tn = tile / ntm; }
+    int Mv = g.M, Nv = g.N;
+    if (g.batch_dim) { Mv = g.batch_dim[batch] - g.dim_off; Nv = Mv; }
+    if (tm * C::BM >= Mv || tn * C::BN >= Nv) return;
+
+    int K = g.K;
+    if (g.batch_k) { K = g.batch_k[batch]; if (K <= 0) return; }
+    const int nkt = K / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wz = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+    const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+    const double* __restrict__ Ab = g.A + (long)batch * g.strideA;
+    const double* __restrict__ Bb = g.B + (long)batch * g.strideB;
+    const int zg = batch * WZ + wz;                   // weight column / output index of this wave
+    const bool zvalid = !WEIGHTED || zg < g.nz_total;
+
+    // ---- loader geometry: a row of BM (BN) doubles is BM/2 (BN/2) 16-byte pieces
+    double2 ra[C::A_LD], rb[C::B_LD];
+    double rw = 0.0;
+    auto gload = [&](int kt) {
+        const long krow = (long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < C::A_LD; ++i) {
+            const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
+            const int col = m0 + c;
+            ra[i] = (col < g.a_cols) ? *reinterpret_cast<const double2*>(Ab + (krow + r) * g.lda + col) : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+            const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
+            const int col = n0 + c;
+            rb[i] = (col < g.b_cols) ? *reinterpret_cast<const double2*>(Bb + (krow + r) * g.ldb + col) : double2{0.0, 0.0};
+        }
+        if (WEIGHTED && tid < BK * WZ) {
+            const int r = tid / WZ, z = tid % WZ, zc = batch * WZ + z;
+            rw = (zc < g.nz_total) ? g.W[(krow + r) * g.ldw + zc] : 0.0;
+        }
+    };
+    auto lstore = [&](int buf) {
+        double* As = smem + buf * C::STAGE;
+        double* Bs = As + C::A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < C::A_LD; ++i) {
+            const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
+            *reinterpret_cast<double2*>(As + r * C::SA + c) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+            const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
+            *reinterpret_cast<double2*>(Bs + r * C::SB + c) = rb[i];
+        }
+        if (WEIGHTED && tid < BK * WZ) (Bs + C::B_ELEMS)[tid] = rw;
+    };
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int frow = lane >> 4, fcol = lane & 15;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+        const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
+        const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
+        const double* Ws = smem + buf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int kr = kk * 4 + frow;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kr * C::SA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kr * C::SB + j * 16];
+            if (WEIGHTED) {
+                const double wv = Ws[kr * WZ + wz];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] *= wv;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  f64 C/D fragment: row = (lane>>4) + 4*reg, col = lane&15 (verified on hardware)
+    if (!zvalid) return;
+    double* __restrict__ Cb = g.C + (WEIGHTED ? (long)zg : (long)batch) * g.strideC;
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 64 + i * 16 + frow + 4 * r;
+            if (row >= Mv) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + fcol;
+                if (col >= Nv) continue;
+                double* p = Cb + (long)row * g.ldc + col;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * *p;
+                *p = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int WZ, bool WEIGHTED>
+int launch(const PglGemmArgs& a, hipStream_t st) {
+    using C = Cfg<WM, WN, WZ, WEIGHTED>;
+    static bool attr_set = false;
+    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", C::LDS_BYTES, hipGetErrorString(e)); return PGL_ERR_HIP; }
+        attr_set = true;
+    }
+    const int ntm = (a.M + C::BM - 1) / C::BM, ntn = (a.N + C::BN - 1) / C::BN;
+    const long ntiles = a.tri ? (long)ntm * (ntm + 1) / 2 : (long)ntm * ntn;
+    const long total = ntiles * a.nbatch;
+    if (total <= 0) return PGL_OK;
+    const long chunk = (total + 7) / 8;
+    const long grid = chunk * 8;
+    if (grid > 0x7fffffffL) { pgl_set_error("gemm grid too large: %ld", grid); return PGL_ERR_ARG; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, st, a);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+}  // namespace
+
+int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
+    PGL_CHECK_ARG(a.K % BK == 0 && a.M > 0 && a.N > 0 && a.nbatch > 0);
+    PGL_CHECK_ARG(a.a_cols % 2 == 0 && a.b_cols % 2 == 0 && a.lda % 2 == 0 && a.ldb % 2 == 0);
+    PGL_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0);
+    switch (kind) {
+        case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); return launch<2, 2, 2, true>(a, st);
+        case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
+        case PGL_GEMM_TRI1: PGL_CHECK_ARG(a.M == a.N); return launch<2, 2, 1, false>(a, st);
+    }
+    pgl_set_error("unknown gemm kind %d", (int)kind);
+    return PGL_ERR_ARG;
+}

@@ -1,0 +1,292 @@
+"""Device-side state and sweep orchestration for one shard of postsynaptic neurons on one MI355X.
+
+The reference runs `for n in range(N): regressions[n].resample(...)` in Python (pyglm/models.py:169-171); here the
+shard's neurons go through the HIP kernels in batches: one activation contraction + one PG/log-likelihood pass for
+the whole shard, then per batch the omega-weighted Gram, posterior assembly, tableau flips and the Gaussian draw.
+PyTorch is used for device memory and streams only; all arithmetic is in libpyglm_hip.so (include/pyglm_hip.h).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FlipState, CholState, call, ptr
+
+F64 = torch.float64
+I32 = torch.int32
+
+
+def _r(x, m):
+    return (x + m - 1) // m * m
+
+
+def make_draws(seed, sweep, neuron_ids, N, D):
+    """Host random inputs of the non-PG steps, keyed by (seed, sweep, GLOBAL neuron) so that results do not depend on
+    how neurons are sharded: perm = permutation(N) (regression.py:286), u = N uniforms (:315), z = D+1 normals (:334,
+    the first sum(a)*B+1 are used)."""
+    nloc = len(neuron_ids)
+    perm = np.empty((nloc, N), dtype=np.int32)
+    u = np.empty((nloc, N))
+    z = np.empty((nloc, D + 1))
+    for i, n in enumerate(neuron_ids):
+        rng = np.random.Generator(np.random.Philox(key=int(seed) & (2 ** 64 - 1), counter=[int(sweep), int(n), 0, 0]))
+        perm[i] = rng.permutation(N)
+        u[i] = rng.random(N)
+        z[i] = rng.standard_normal(D + 1)
+    return perm, u, z
+
+
+def prior_terms(S_w, mu_w, S_b, mu_b):
+    """natural parameters (regression.py:138-151) + the per-block prior constant of the collapsed flips.
+    S_w (n,N,B,B), mu_w (n,N,B), S_b (n,), mu_b (n,)  ->  Jw, hw, Jb, hb, c0 (n,N)."""
+    Jw = np.linalg.inv(S_w)
+    hw = np.einsum("nmij,nmj->nmi", Jw, mu_w)
+    Jb = 1.0 / S_b
+    hb = Jb * mu_b
+    _, logdet = np.linalg.slogdet(Jw)
+    c0 = 0.5 * logdet - 0.5 * np.einsum("nmi,nmi->nm", mu_w, hw)
+    return Jw, hw, Jb, hb, c0
+
+
+class _Dataset(object):
+    pass
+
+
+class GibbsEngine(object):
+    OBS = {"bernoulli": 0, "negbin": 1}
+
+    def __init__(self, N, B, n0=0, n1=None, device="cuda:0", obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None):
+        if not torch.cuda.is_available():
+            raise _lib.PglError("pyglm_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        _lib.load()
+        self.N, self.B, self.D = int(N), int(B), int(N) * int(B)
+        self.n0, self.n1 = int(n0), int(N if n1 is None else n1)
+        self.nloc = self.n1 - self.n0
+        assert 0 <= self.n0 < self.n1 <= self.N
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        self.obs, self.xi = self.OBS[obs], float(xi)
+        self.Dp = _r(self.D + 1, 16)
+        self.ldn = _r(self.nloc, 2)
+        self.ldj = _r(self.D + 2, 16)
+        self.kmax = _lib.load().pgl_flip_kmax()
+        self.R = _lib.load().pgl_flip_window_blocks(self.B)
+        if self.R < 1:
+            raise ValueError("B=%d too large for the proposal window" % self.B)
+        self.datasets = []
+        self.stream = torch.cuda.current_stream(self.dev)
+        per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + self.kmax * self.kmax * 8
+        if batch is None:
+            free, _ = torch.cuda.mem_get_info(self.dev)
+            budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * 0.45)
+            batch = max(2, min(self.nloc, budget // per_neuron))
+        self.nb = int(min(batch, self.nloc))
+        self._alloc_batch()
+        self.timings = {}
+
+    # ------------------------------------------------------------------ buffers
+    def _z(self, *shape, dtype=F64):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def _alloc_batch(self):
+        nb, ldj, N, D, kmax = self.nb, self.ldj, self.N, self.D, self.kmax
+        self.Jbuf = self._z(nb, ldj, ldj)
+        self.Mtab = self._z(nb, ldj, ldj)
+        self.Ac = self._z(nb, ldj, ldj)
+        self.hc = self._z(2, nb, ldj)
+        self.G = self._z(nb, kmax, kmax)
+        self.Ut = self._z(nb, kmax, ldj)
+        self.Wt_ws = self._z(nb, kmax, ldj)
+        self.d_idx = self._z(nb, kmax, dtype=I32)
+        self.d_sign = self._z(nb, kmax)
+        self.d_cnt = self._z(nb, dtype=I32)
+        self.batch_k = self._z(nb, dtype=I32)
+        self.act = self._z(nb, D + 1, dtype=I32)
+        self.na = self._z(nb, dtype=I32)
+        # whole-shard state
+        nl = self.nloc
+        self.a_dev = self._z(nl, N, dtype=I32)
+        self.W_dev = self._z(nl, D)
+        self.b_dev = self._z(nl)
+        self.status = self._z(nl, dtype=I32)
+        self.Wt = self._z(self.Dp, self.ldn)          # k-major weights for the activation contraction
+        self.bias = self._z(nl)
+        self.border = self._z(2 * self.ldn, self.Dp)
+        self.ll = self._z(nl)
+
+    def _st(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ------------------------------------------------------------------ data
+    def add_data(self, Y, X=None, basis=None):
+        """models.py:66-80: Y is (T, N) counts; X (T, N, B) optional, else built on the device from `basis` (L, B)
+        by pgl_design_matrix (utils/basis.py:5-34)."""
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        T = Y.shape[0]
+        assert Y.shape == (T, self.N)
+        ds = _Dataset()
+        ds.T, ds.Tp = T, _r(T, 16)
+        ds.X = self._z(ds.Tp, self.Dp)
+        ds.Xt = self._z(self.Dp, ds.Tp)
+        st = self._st()
+        if X is None:
+            assert basis is not None
+            basis = np.ascontiguousarray(basis, dtype=np.float64)
+            R, B = basis.shape
+            assert B == self.B
+            clip = int(basis.min() >= 0 and Y.min() >= 0)
+            S_dev = torch.from_numpy(Y).to(self.dev)
+            b_dev = torch.from_numpy(basis).to(self.dev)
+            call("pgl_design_matrix", ptr(S_dev), self.N, ptr(b_dev), ptr(ds.X), self.Dp, ptr(ds.Xt), ds.Tp, T, self.N, self.B, R, clip, st)
+            torch.cuda.synchronize(self.dev)
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64).reshape(T, self.D)
+            ds.X[:T, :self.D] = torch.from_numpy(X).to(self.dev)
+            ds.X[:T, self.D] = 1.0
+            call("pgl_transpose", ptr(ds.X), self.Dp, ptr(ds.Xt), ds.Tp, T, self.D + 1, st)
+        ds.Y = self._z(T, self.ldn)
+        ds.Y[:, :self.nloc] = torch.from_numpy(np.ascontiguousarray(Y[:, self.n0:self.n1])).to(self.dev)
+        ds.Psi = self._z(T, self.ldn)
+        ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
+        ds.llpart = self._z(_lib.load().pgl_pg_loglik_partials(T), self.nloc)
+        ds.elem0 = sum(d.T for d in self.datasets)
+        self.datasets.append(ds)
+        return ds
+
+    def design_matrix(self, i=0):
+        ds = self.datasets[i]
+        return ds.X[:ds.T, :self.D].cpu().numpy().reshape(ds.T, self.N, self.B)
+
+    # ------------------------------------------------------------------ activation / PG / log-likelihood
+    def _upload_weights(self, a, W, b):
+        aw = (np.asarray(a, dtype=np.float64)[:, :, None] * np.asarray(W, dtype=np.float64)).reshape(self.nloc, self.D)
+        Wt = np.zeros((self.Dp, self.ldn))
+        Wt[:self.D, :self.nloc] = aw.T
+        self.Wt.copy_(torch.from_numpy(Wt))
+        self.bias.copy_(torch.from_numpy(np.asarray(b, dtype=np.float64).reshape(self.nloc)))
+
+    def _psi_pass(self, draw, seed, sweep):
+        """activation (regression.py:195-201) for the whole shard + PG/kappa/log-lik (:491-511). Returns ll (nloc,) device."""
+        st = self._st()
+        for i, ds in enumerate(self.datasets):
+            call("pgl_activation", ptr(ds.Xt), ds.Tp, ptr(self.Wt), self.ldn, ptr(ds.Psi), self.ldn, ds.T, self.Dp, self.nloc, st)
+            om = ds.OK if draw else None
+            kp = ctypes.c_void_p(ds.OK.data_ptr() + 8 * self.ldn) if draw else None
+            call("pgl_pg_loglik", ptr(ds.Psi), self.ldn, ptr(self.bias), ptr(ds.Y), self.ldn, ptr(om), 2 * self.ldn, kp, 2 * self.ldn,
+                 ptr(ds.llpart), ptr(self.ll), int(i > 0), ds.T, self.nloc, self.obs, self.xi, int(seed), int(sweep), self.n0, ds.elem0, st)
+        return self.ll
+
+    def log_likelihood(self, a, W, b):
+        """per-neuron sum_t log p(y_t | psi_t) (regression.py:491-494 summed as at models.py:93-94)."""
+        self._upload_weights(a, W, b)
+        return self._psi_pass(False, 0, 0).cpu().numpy().copy()
+
+    def psi(self, a, W, b, i=0):
+        self._upload_weights(a, W, b)
+        self._psi_pass(False, 0, 0)
+        ds = self.datasets[i]
+        return ds.Psi[:, :self.nloc].cpu().numpy()
+
+    # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
+    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None):
+        """regression.py:265-280 for every local neuron.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in
+        natural form (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
+        omega_override: list of (T, nloc) arrays replacing the PG draws (test hook: the reference fixtures inject omega)."""
+        nloc, N, B, D, ldn, Dp, ldj = self.nloc, self.N, self.B, self.D, self.ldn, self.Dp, self.ldj
+        st = self._st()
+        a = np.asarray(a).astype(bool).copy()
+        rho = np.asarray(rho, dtype=np.float64)
+        det = np.all((rho < 1e-6) | (rho > 1 - 1e-6), axis=1)           # regression.py:153-155
+        self._upload_weights(a, W, b)
+        self._psi_pass(True, seed, sweep)
+        ll_before = self.ll.cpu().numpy().copy()
+        if omega_override is not None:
+            for ds, om in zip(self.datasets, omega_override):
+                ds.OK[:ds.T, :nloc] = torch.from_numpy(np.ascontiguousarray(om, dtype=np.float64)).to(self.dev)
+        # border sums  [Omega|Kappa]' [X, 1]   (regression.py:253-260)
+        for i, ds in enumerate(self.datasets):
+            call("pgl_contract_tn", ptr(ds.OK), 2 * ldn, 2 * ldn, ptr(ds.X), Dp, Dp, ptr(self.border), Dp, 2 * ldn, D + 1, ds.Tp,
+                 1.0, 1.0 if i > 0 else 0.0, st)
+        a[det] = np.round(rho[det]).astype(bool)                         # regression.py:274-275
+        a_i32 = torch.from_numpy(a.astype(np.int32)).to(self.dev)
+        self.a_dev.copy_(a_i32)
+        self.status.zero_()
+        d = dict(rho=rho, Jw=Jw, hw=hw, Jb=Jb, hb=hb, c0=c0, perm=perm, u=u, z=z)
+        dev = {}
+        for k, v in d.items():
+            arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
+            dev[k] = torch.from_numpy(arr).to(self.dev)
+        skip = torch.from_numpy(det.astype(np.int32)).to(self.dev)
+        for s in range(0, nloc, self.nb):
+            nbb = min(self.nb, nloc - s)
+            self._batch(s, nbb, a, det, dev, skip, st)
+        torch.cuda.synchronize(self.dev)
+        status = self.status.cpu().numpy()
+        if status.any():
+            bad = np.nonzero(status)[0]
+            raise np.linalg.LinAlgError("posterior system not positive definite for local neurons %s (flags %s)"
+                                        % (bad[:8].tolist(), status[bad[:8]].tolist()))
+        a_new = self.a_dev.cpu().numpy().astype(bool)
+        W_new = self.W_dev.cpu().numpy().reshape(nloc, N, B).copy()
+        b_new = self.b_dev.cpu().numpy().copy()
+        return a_new, W_new, b_new, ll_before
+
+    def _batch(self, s, nbb, a_host, det, dev, skip, st):
+        N, B, D, ldn, Dp, ldj, kmax = self.N, self.B, self.D, self.ldn, self.Dp, self.ldj, self.kmax
+        strideJ = ldj * ldj
+        off8 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 8 * int(elems))
+        off4 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
+        # ---- omega-weighted Gram (regression.py:251-252)
+        for i, ds in enumerate(self.datasets):
+            call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, off8(ds.OK, s), 2 * ldn, ds.Tp, D, nbb, ptr(self.Jbuf), ldj, strideJ, int(i > 0), st)
+        # ---- posterior assembly (regression.py:210-223, 253-260, 270-271)
+        call("pgl_assemble_posterior", ptr(self.Jbuf), ldj, strideJ, off8(self.border, s * Dp), off8(self.border, (ldn + s) * Dp), Dp,
+             off8(dev["Jw"], s * N * B * B), off8(dev["hw"], s * N * B), off8(dev["Jb"], s), off8(dev["hb"], s), nbb, N, B, st)
+        # ---- collapsed flips (regression.py:282-320)
+        if not det[s:s + nbb].all():
+            self.Mtab[:nbb].copy_(self.Jbuf[:nbb])
+            fs = FlipState(ptr(self.Mtab), ldj, strideJ, nbb, N, B, off4(dev["perm"], s * N), off8(dev["u"], s * N), off8(dev["rho"], s * N),
+                           off8(dev["c0"], s * N), off4(self.a_dev, s * N), off4(skip, s), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt),
+                           ptr(self.batch_k), ptr(self.G), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s))
+            # initial sweep on S0 = {bias} U {active blocks}, in chunks of kmax pivots
+            lists = []
+            for i in range(nbb):
+                if det[s + i]:
+                    lists.append(np.zeros(0, dtype=np.int32))
+                else:
+                    blocks = np.nonzero(a_host[s + i])[0]
+                    rows = (blocks[:, None] * B + np.arange(B)[None, :]).ravel()
+                    lists.append(np.concatenate(([D], rows)).astype(np.int32))
+            nchunk = max((len(l) + kmax - 1) // kmax for l in lists)
+            for c in range(nchunk):
+                idx = np.zeros((self.nb, kmax), dtype=np.int32)
+                cnt = np.zeros(self.nb, dtype=np.int32)
+                for i, l in enumerate(lists):
+                    part = l[c * kmax:(c + 1) * kmax]
+                    idx[i, :len(part)] = part
+                    cnt[i] = len(part)
+                self.d_idx.copy_(torch.from_numpy(idx))
+                self.d_cnt.copy_(torch.from_numpy(cnt))
+                self.d_sign.fill_(1.0)
+                call("pgl_flip_apply", ctypes.byref(fs), st)
+            nwin = (N + self.R - 1) // self.R
+            for w in range(nwin):
+                call("pgl_flip_decide", ctypes.byref(fs), w, st)
+                call("pgl_flip_apply", ctypes.byref(fs), st)
+        # ---- weights (regression.py:323-340)
+        cs = CholState(ptr(self.Jbuf), ldj, strideJ, off4(self.a_dev, s * N), ptr(self.act), D + 1, ptr(self.na), ptr(self.Ac), ldj, strideJ,
+                       ptr(self.hc), off8(dev["z"], s * (D + 1)), D + 1, off8(self.W_dev, s * D), off8(self.b_dev, s), nbb, N, B,
+                       off4(self.status, s))
+        call("pgl_active_index", ctypes.byref(cs), st)
+        na_max = int(self.na[:nbb].max().item())
+        call("pgl_sample_weights", ctypes.byref(cs), na_max, st)
+
+    # test hooks --------------------------------------------------------------------------------------------------
+    def posterior(self, i):
+        """assembled (J_post (D+1,D+1), h_post (D+1,)) of batch slot i as dense symmetric host arrays"""
+        D = self.D
+        M = self.Jbuf[i, :D + 2, :D + 2].cpu().numpy()
+        L = np.tril(M)
+        full = L + np.tril(L, -1).T
+        return full[:D + 1, :D + 1], full[D + 1, :D + 1]
