@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Headline benchmark: full Gibbs sweeps/sec (SparseBernoulliGLM.resample_model) at N=1024, T=100k, B=5 on synthetic
+spike trains, neurons sharded over --gpus MI355X (one process per GPU; launch with torch.distributed.run for N>1).
+
+One JSON line on rank 0 (contract in the task statement): value = sweeps/s of the WHOLE model, `roofline` for the dominant
+kernel (omega-weighted fp64 Gram, MFMA-bound), `cpu_baseline` = the oracle timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {   # BASELINE.json configs
+    "cfg1": dict(N=4, B=1, T=10000, L=100),
+    "cfg2": dict(N=128, B=5, T=50000, L=100),
+    "cfg3": dict(N=1024, B=5, T=100000, L=100),
+}
+PEAK_F64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 64 cyc (tools/ubench2_f64.hip, measured)
+
+
+def synth(N, B, T, L, seed=0):
+    """i.i.d. Bernoulli(0.08) spikes, cosine basis / L, priors of examples/synthetic.py:40-42."""
+    from pyglm_amd.utils.basis import cosine_basis
+    rng = np.random.default_rng(seed)
+    basis = cosine_basis(B, L=L) / L
+    Y = (rng.random((T, N)) < 0.08).astype(np.float64)
+    return basis, Y
+
+
+def cpu_baseline(model, cfg, budget_s=20.0):
+    """The oracle (NumPy/BLAS restatement of the reference, oracle/pyglm_oracle.py) on this host's cores, for ONE neuron of the
+    same workload, on a bounded sample: T_s time bins of the Gram/activation (cost linear in T) and P of the N flip proposals
+    (each proposal costs the same), extrapolated to one full sweep of N neurons.  Labelled as extrapolated."""
+    from oracle import pyglm_oracle as orc
+    N, B, T = cfg["N"], cfg["B"], cfg["T"]
+    D = N * B
+    eng = model.engine
+    Ts = int(min(T, max(2000, 4e10 / (2.0 * D * D))))         # ~4e10 flop of dgemm
+    P = min(N, 8)
+    X = eng.datasets[0].X[:Ts, :D].cpu().numpy()
+    om = eng.datasets[0].OK[:Ts, 0].cpu().numpy()
+    y = model.data_list[0][1][:Ts, model.n0].astype(float)
+    r0 = model.regressions[model.n0]
+    r = orc.Regression(N, B, rho=r0.rho.copy(), mu_w=r0.mu_w.copy(), S_w=r0.S_w.copy(), mu_b=r0.mu_b.copy(), S_b=r0.S_b.copy())
+    r.a, r.W, r.b = r0.a.copy(), r0.W.copy(), r0.b.copy()
+    rng = np.random.default_rng(1)
+    t0 = time.perf_counter()
+    psi = r.activation(X)
+    _ = orc.pg_draw(None, psi, 1, 0)
+    t_act = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Jp, hp = r.prior_stats()
+    Jl, hl = r.lkhd_stats([(X, y)], [om])
+    t_gram = time.perf_counter() - t0
+    Jq, hq = Jp + Jl * (T / Ts), hp + hl * (T / Ts)
+    t0 = time.perf_counter()
+    r.collapsed_resample_a(Jp, hp, Jq, hq, rng.permutation(N)[:P], rng.random(P))
+    t_flip = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r.resample_W(Jq, hq, rng.standard_normal(D + 1))
+    t_w = time.perf_counter() - t0
+    t_neuron = (t_act + t_gram) * (T / Ts) + t_flip * (N / P) + t_w
+    return dict(value=1.0 / (N * t_neuron), unit="sweeps/s", cores=os.cpu_count(), kind="port",
+                sample="oracle (NumPy/OpenBLAS all cores + OpenMP PG), 1 of %d neurons, T_s=%d of %d bins for activation/PG/Gram "
+                       "(x%.0f), %d of %d flip proposals (x%.0f), full weight draw; extrapolated to N neurons; "
+                       "per-neuron s: act+pg %.3f gram %.3f flips %.3f weights %.3f" %
+                       (N, Ts, T, T / Ts, P, N, N / P, t_act * T / Ts, t_gram * T / Ts, t_flip * N / P, t_w))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--N", type=int)
+    ap.add_argument("--T", type=int)
+    ap.add_argument("--B", type=int)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=None)
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("N", "T", "B"):
+        if getattr(args, k):
+            cfg[k] = getattr(args, k)
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from pyglm_amd.models import SparseBernoulliGLM
+    N, B, T, L = cfg["N"], cfg["B"], cfg["T"], cfg["L"]
+    np.random.seed(0)
+    basis, Y = synth(N, B, T, L)
+    t_setup = time.perf_counter()
+    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=0,
+                               engine_kwargs=dict(batch=args.batch) if args.batch else None)
+    model.add_data(Y)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.resample_model()
+    model.engine.profile = True
+    model.engine.collect_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.resample_model()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = model.engine.collect_timings()
+    model.engine.profile = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ll = model.log_likelihood()
+
+    if rank == 0:
+        g = stages.get("gram", dict(ms=0.0, calls=0, work=0.0))
+        achieved = (g["work"] / (g["ms"] * 1e-3) * 1e-12) if g["ms"] > 0 else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "gram_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Gibbs sweeps/sec (full resample_model)", "value": args.steps / dt, "unit": "sweeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SparseBernoulliGLM N=%d B=%d L=%d T=%d, i.i.d. Bernoulli(0.08) spikes, neurons sharded over %d GPU(s)"
+                                   % (N, B, L, T, world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
+                       "neurons_per_batch": model.engine.nb},
+            "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64<2,2,2,weighted> (omega-weighted Gram)", "achieved": achieved,
+                         "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
+                         "traffic": traffic, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
+            "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
+            "setup_s": round(t_setup, 2), "log_likelihood_after": ll,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, cfg)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,7 +56,8 @@ class _Dataset(object):
 class GibbsEngine(object):
     OBS = {"bernoulli": 0, "negbin": 1}
 
-    def __init__(self, N, B, n0=0, n1=None, device="cuda:0", obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None):
+    def __init__(self, N, B, n0=0, n1=None, device="cuda:0", obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None,
+                 design_only=False):
         if not torch.cuda.is_available():
             raise _lib.PglError("pyglm_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         _lib.load()
@@ -82,8 +83,38 @@ class GibbsEngine(object):
             budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * 0.45)
             batch = max(2, min(self.nloc, budget // per_neuron))
         self.nb = int(min(batch, self.nloc))
-        self._alloc_batch()
+        self.design_only = design_only
+        if not design_only:
+            self._alloc_batch()
         self.timings = {}
+        self.profile = False
+        self._ev = []
+
+    # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
+    def _tic(self, name, work=0.0):
+        if not self.profile:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.dev))
+        return (name, e0, e1, work)
+
+    def _toc(self, h):
+        if h is not None:
+            h[2].record(torch.cuda.current_stream(self.dev))
+            self._ev.append(h)
+
+    def collect_timings(self):
+        """-> {stage: dict(ms=total, calls=n, work=sum)} since the last call"""
+        torch.cuda.synchronize(self.dev)
+        out = {}
+        for name, e0, e1, work in self._ev:
+            d = out.setdefault(name, dict(ms=0.0, calls=0, work=0.0))
+            d["ms"] += e0.elapsed_time(e1)
+            d["calls"] += 1
+            d["work"] += work
+        self._ev = []
+        return out
 
     # ------------------------------------------------------------------ buffers
     def _z(self, *shape, dtype=F64):
@@ -145,13 +176,15 @@ class GibbsEngine(object):
             ds.X[:T, :self.D] = torch.from_numpy(X).to(self.dev)
             ds.X[:T, self.D] = 1.0
             call("pgl_transpose", ptr(ds.X), self.Dp, ptr(ds.Xt), ds.Tp, T, self.D + 1, st)
+        ds.elem0 = sum(d.T for d in self.datasets)
+        self.datasets.append(ds)
+        if self.design_only:
+            return ds
         ds.Y = self._z(T, self.ldn)
         ds.Y[:, :self.nloc] = torch.from_numpy(np.ascontiguousarray(Y[:, self.n0:self.n1])).to(self.dev)
         ds.Psi = self._z(T, self.ldn)
         ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
         ds.llpart = self._z(_lib.load().pgl_pg_loglik_partials(T), self.nloc)
-        ds.elem0 = sum(d.T for d in self.datasets)
-        self.datasets.append(ds)
         return ds
 
     def design_matrix(self, i=0):
@@ -170,11 +203,15 @@ class GibbsEngine(object):
         """activation (regression.py:195-201) for the whole shard + PG/kappa/log-lik (:491-511). Returns ll (nloc,) device."""
         st = self._st()
         for i, ds in enumerate(self.datasets):
+            h = self._tic("activation", 2.0 * ds.T * self.D * self.nloc)
             call("pgl_activation", ptr(ds.Xt), ds.Tp, ptr(self.Wt), self.ldn, ptr(ds.Psi), self.ldn, ds.T, self.Dp, self.nloc, st)
+            self._toc(h)
+            h = self._tic("pg_loglik", float(ds.T) * self.nloc)
             om = ds.OK if draw else None
             kp = ctypes.c_void_p(ds.OK.data_ptr() + 8 * self.ldn) if draw else None
             call("pgl_pg_loglik", ptr(ds.Psi), self.ldn, ptr(self.bias), ptr(ds.Y), self.ldn, ptr(om), 2 * self.ldn, kp, 2 * self.ldn,
                  ptr(ds.llpart), ptr(self.ll), int(i > 0), ds.T, self.nloc, self.obs, self.xi, int(seed), int(sweep), self.n0, ds.elem0, st)
+            self._toc(h)
         return self.ll
 
     def log_likelihood(self, a, W, b):
@@ -239,11 +276,14 @@ class GibbsEngine(object):
         off4 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
         # ---- omega-weighted Gram (regression.py:251-252)
         for i, ds in enumerate(self.datasets):
+            h = self._tic("gram", float(nbb) * ds.T * D * (D + 1))     # algorithmic flops: lower triangle, 2 flop per MAC
             call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, off8(ds.OK, s), 2 * ldn, ds.Tp, D, nbb, ptr(self.Jbuf), ldj, strideJ, int(i > 0), st)
+            self._toc(h)
         # ---- posterior assembly (regression.py:210-223, 253-260, 270-271)
         call("pgl_assemble_posterior", ptr(self.Jbuf), ldj, strideJ, off8(self.border, s * Dp), off8(self.border, (ldn + s) * Dp), Dp,
              off8(dev["Jw"], s * N * B * B), off8(dev["hw"], s * N * B), off8(dev["Jb"], s), off8(dev["hb"], s), nbb, N, B, st)
         # ---- collapsed flips (regression.py:282-320)
+        hf = self._tic("flips")
         if not det[s:s + nbb].all():
             self.Mtab[:nbb].copy_(self.Jbuf[:nbb])
             fs = FlipState(ptr(self.Mtab), ldj, strideJ, nbb, N, B, off4(dev["perm"], s * N), off8(dev["u"], s * N), off8(dev["rho"], s * N),
@@ -274,6 +314,8 @@ class GibbsEngine(object):
             for w in range(nwin):
                 call("pgl_flip_decide", ctypes.byref(fs), w, st)
                 call("pgl_flip_apply", ctypes.byref(fs), st)
+        self._toc(hf)
+        hc_ = self._tic("weights")
         # ---- weights (regression.py:323-340)
         cs = CholState(ptr(self.Jbuf), ldj, strideJ, off4(self.a_dev, s * N), ptr(self.act), D + 1, ptr(self.na), ptr(self.Ac), ldj, strideJ,
                        ptr(self.hc), off8(dev["z"], s * (D + 1)), D + 1, off8(self.W_dev, s * D), off8(self.b_dev, s), nbb, N, B,
@@ -281,6 +323,7 @@ class GibbsEngine(object):
         call("pgl_active_index", ctypes.byref(cs), st)
         na_max = int(self.na[:nbb].max().item())
         call("pgl_sample_weights", ctypes.byref(cs), na_max, st)
+        self._toc(hc_)
 
     # test hooks --------------------------------------------------------------------------------------------------
     def posterior(self, i):

@@ -1,0 +1,305 @@
+"""Population models with the reference's interface (pyglm/models.py): SparseBernoulliGLM & friends.
+
+`add_data() / resample_model() / log_likelihood()` are drop-ins; underneath, the N per-neuron regressions are not
+looped over in Python (models.py:169-171) but sent through the HIP kernels in batches by a `GibbsEngine`, and they
+shard by postsynaptic neuron over the ranks of a torch.distributed process group (one process per GPU):
+
+    rank r owns neurons [r*N/G, (r+1)*N/G)   -- its Y columns, its rows of (A, W, b); X is replicated.
+    per sweep:  all_gather of the shard's (a, W, b) rows (the network prior needs the full (A, W), models.py:230)
+                all_reduce of one fp64 scalar in log_likelihood().
+Random inputs are keyed by (seed, sweep, global neuron), so results do not depend on the number of ranks.
+"""
+import numpy as np
+import numpy.random as npr
+
+from . import networks as _networks
+from . import regression as _regression
+from .utils.utils import logistic
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except ImportError:
+        pass
+    return None
+
+
+def shard_bounds(N, world, rank):
+    """contiguous, balanced neuron ranges"""
+    base, rem = divmod(N, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class NonlinearAutoregressiveModel(object):
+    """(models.py:8-201) y_n[t] ~ p(f(w_n . x[t])), x = basis-filtered history of all neurons."""
+
+    def __init__(self, N, regressions, basis=None, B=10, device=None, engine_factory=None, seed=None, engine_kwargs=None):
+        self.N = N
+        assert len(regressions) == N
+        self.regressions = regressions
+        if basis is None:
+            basis = np.eye(B)
+        else:
+            assert basis.ndim == 2
+        self.basis = basis
+        self.B = self.basis.shape[1]
+        self.data_list = []
+        # ---- device / distribution
+        dist = _dist()
+        self.world = dist.get_world_size() if dist else 1
+        self.rank = dist.get_rank() if dist else 0
+        self.n0, self.n1 = shard_bounds(N, self.world, self.rank)
+        self._device = device
+        self._engine_factory = engine_factory
+        self._engine_kwargs = engine_kwargs or {}
+        self._engine = None
+        # like the reference's PG samplers (regression.py:476) the stream seed comes from NumPy's global RNG
+        self.seed = int(npr.randint(2 ** 31)) if seed is None else int(seed)
+        if dist and seed is None:
+            import torch
+            t = torch.tensor([self.seed], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, 0)
+            self.seed = int(t.item())
+        self.sweeps_done = 0
+
+    # ---- engine
+    @property
+    def engine(self):
+        if self._engine is None:
+            reg = self.regressions[0]
+            kw = dict(obs=getattr(reg, "_obs", "bernoulli") or "bernoulli", xi=getattr(reg, "xi", 1.0))
+            kw.update(self._engine_kwargs)
+            if self._engine_factory is not None:
+                self._engine = self._engine_factory(self.N, self.B, self.n0, self.n1, **kw)
+            else:
+                from .engine import GibbsEngine
+                import torch
+                dev = self._device or ("cuda:%d" % torch.cuda.current_device())
+                self._engine = GibbsEngine(self.N, self.B, self.n0, self.n1, device=dev, **kw)
+        return self._engine
+
+    # ---- state read-backs (models.py:54-64): row = postsynaptic
+    @property
+    def weights(self):
+        return np.array([r.W for r in self.regressions])
+
+    @property
+    def adjacency(self):
+        return np.array([r.a for r in self.regressions])
+
+    @property
+    def biases(self):
+        return np.array([r.b for r in self.regressions]).ravel()
+
+    def add_data(self, data, X=None):
+        """(models.py:66-80)"""
+        N, B = self.N, self.B
+        assert isinstance(data, np.ndarray) and data.ndim == 2 and data.shape[1] == self.N
+        T = data.shape[0]
+        if X is not None:
+            assert X.shape == (T, N, B)
+        self.engine.add_data(data, X=X, basis=self.basis)
+        self.data_list.append((_LazyX(self.engine, len(self.engine.datasets) - 1) if X is None else X, data))
+
+    # ---- local <-> global state
+    def _local_state(self):
+        regs = self.regressions[self.n0:self.n1]
+        a = np.array([r.a for r in regs]).astype(bool)
+        W = np.array([r.W for r in regs])
+        b = np.array([r.b for r in regs]).reshape(-1)
+        return a, W, b
+
+    def _gather_rows(self, arr):
+        """all_gather of per-neuron rows over the shard axis (ranks may own different counts)"""
+        dist = _dist()
+        if dist is None or self.world == 1:
+            return arr
+        import torch
+        nccl = dist.get_backend() == "nccl"
+        counts = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
+        maxc = max(hi - lo for lo, hi in counts)
+        pad = np.zeros((maxc,) + arr.shape[1:], dtype=arr.dtype)
+        pad[:arr.shape[0]] = arr
+        t = torch.from_numpy(np.ascontiguousarray(pad))
+        if nccl:
+            t = t.cuda()
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t)
+        return np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(outs, counts)], axis=0)
+
+    def log_likelihood(self, datas=None):
+        """(models.py:82-96) sum over datasets and neurons; `datas` other than the stored data is evaluated through a
+        temporary engine."""
+        if datas is None:
+            eng = self.engine
+        else:
+            from .engine import GibbsEngine
+            eng = (self._engine_factory or GibbsEngine)(self.N, self.B, self.n0, self.n1, obs=self.engine_obs())
+            for d in datas:
+                if isinstance(d, tuple):
+                    eng.add_data(d[1], X=d[0] if not isinstance(d[0], _LazyX) else None, basis=self.basis)
+                else:
+                    eng.add_data(d, basis=self.basis)
+        a, W, b = self._local_state()
+        ll = float(np.sum(eng.log_likelihood(a, W, b)))
+        dist = _dist()
+        if dist is not None and self.world > 1:
+            import torch
+            t = torch.tensor([ll], dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t)            # the only collective on the likelihood path: one fp64 scalar
+            ll = float(t.item())
+        return ll
+
+    def engine_obs(self):
+        return getattr(self.regressions[0], "_obs", "bernoulli")
+
+    @property
+    def means(self):
+        """(models.py:153-163) E[y | X] per dataset, (T, N)"""
+        a, W, b = self._local_state()
+        mus = []
+        for i in range(len(self.data_list)):
+            psi = self.engine.psi(a, W, b, i)
+            mu = logistic(psi) if self.engine_obs() == "bernoulli" else self.regressions[0].xi * np.exp(psi)
+            mus.append(self._gather_rows(np.ascontiguousarray(mu.T)).T)
+        return mus
+
+    def generate(self, keep=True, T=100, verbose=False, intvl=10):
+        """(models.py:98-151) forward simulation, serial in t (host; not on the Gibbs hot path)."""
+        if T == 0:
+            return np.zeros((0, self.N))
+        assert isinstance(T, int), "Size must be an integer number of time bins"
+        N, B = self.N, self.B
+        L = self.basis.shape[0]
+        flipped = self.basis[::-1]                      # row 0 of the basis = previous bin
+        assert not np.allclose(flipped, self.basis)
+        Wm = self.weights.reshape(N, N * B)               # as the reference: the stored W, not a*W
+        bias = self.biases
+        Y = np.zeros((T + L, N))
+        X = np.zeros((T + L, N, B))
+        for t in range(L, T + L):
+            if verbose and t % intvl == 0:
+                print("Generate t={}".format(t))
+            X[t] = Y[t - L:t].T.dot(flipped)
+            psi = Wm.dot(X[t].reshape(N * B)) + bias
+            Y[t] = self.regressions[0].rvs(psi=psi)
+        if keep:
+            self.add_data(Y[L:], X=X[L:])
+        return X[L:], Y[L:]
+
+    # ---- Gibbs
+    def resample_model(self):
+        self.resample_regressions()
+
+    def resample_regressions(self):
+        """(models.py:169-171) all local neurons through the GPU engine, then an all_gather of the new rows."""
+        from .engine import make_draws, prior_terms
+        regs = self.regressions[self.n0:self.n1]
+        a, W, b = self._local_state()
+        rho = np.array([r.rho for r in regs])
+        S_w = np.array([r.S_w for r in regs])
+        mu_w = np.array([r.mu_w for r in regs])
+        S_b = np.array([r.S_b[0, 0] for r in regs])
+        mu_b = np.array([r.mu_b[0] for r in regs])
+        Jw, hw, Jb, hb, c0 = prior_terms(S_w, mu_w, S_b, mu_b)
+        perm, u, z = make_draws(self.seed, self.sweeps_done, range(self.n0, self.n1), self.N, self.N * self.B)
+        a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done)
+        self.sweeps_done += 1
+        A_all = self._gather_rows(a)
+        W_all = self._gather_rows(W)
+        b_all = self._gather_rows(b)
+        for n, r in enumerate(self.regressions):
+            r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
+
+    def plot(self, *args, **kwargs):
+        raise NotImplementedError("plotting is outside the scope of the MI355X hot path (SURVEY.md section 2, row 8)")
+
+
+class _LazyX(object):
+    """stands for the device-resident design matrix in data_list; materialises on the host only when indexed"""
+
+    def __init__(self, engine, i):
+        self.engine, self.i = engine, i
+
+    def __array__(self, dtype=None, copy=None):
+        return self.engine.design_matrix(self.i)
+
+    @property
+    def shape(self):
+        ds = self.engine.datasets[self.i]
+        return (ds.T, self.engine.N, self.engine.B)
+
+
+class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
+    """(models.py:204-236) adds the network prior over the regressions' hyper-parameters."""
+
+    def __init__(self, N, network, regressions, basis=None, B=10, **kw):
+        super(HierarchicalNonlinearAutoregressiveModel, self).__init__(N, regressions, basis=basis, B=B, **kw)
+        self.network = network
+
+    def resample_model(self):
+        super(HierarchicalNonlinearAutoregressiveModel, self).resample_model()
+        self.resample_network()
+
+    def resample_network(self):
+        """(models.py:228-236).  Every rank holds the full (A, W) after the all_gather and draws the same network
+        parameters from an identically seeded host generator; the push evaluates mu_W / sigma_W / rho once
+        instead of once per row."""
+        net = self.network
+        state = npr.get_state()
+        npr.seed((self.seed * 1000003 + self.sweeps_done) % (2 ** 32))      # identical on every rank
+        try:
+            net.resample((self.adjacency, self.weights))
+        finally:
+            npr.set_state(state)
+        sigma, mu, rho = net.sigma_W, net.mu_W, net.rho
+        for n, reg in enumerate(self.regressions):
+            reg.S_w = sigma[n]
+            reg.mu_w = mu[n]
+            reg.rho = rho[n]
+
+
+GLM = NonlinearAutoregressiveModel
+NetworkGLM = HierarchicalNonlinearAutoregressiveModel
+
+
+class _DefaultMixin(object):
+    _network_class = None
+    _regression_class = None
+
+    def __init__(self, N, B=10, basis=None, network=None, network_kwargs=None, regressions=None, regression_kwargs=None, **kw):
+        """(models.py:246-267)"""
+        B = B if basis is None else basis.shape[1]
+        if network is None:
+            network = self._network_class(N, B, **(network_kwargs or {}))
+        if regressions is None:
+            regressions = [self._regression_class(N, B, **(regression_kwargs or {})) for _ in range(N)]
+        super(_DefaultMixin, self).__init__(N, network, regressions, B=B, basis=basis, **kw)
+
+
+class BernoulliGLM(_DefaultMixin, NetworkGLM):
+    _network_class = _networks.NIWDenseNetwork
+    _regression_class = _regression.BernoulliRegression
+
+
+class SparseBernoulliGLM(_DefaultMixin, NetworkGLM):
+    _network_class = _networks.NIWSparseNetwork
+    _regression_class = _regression.SparseBernoulliRegression
+
+
+class NegativeBinomialGLM(_DefaultMixin, NetworkGLM):
+    _network_class = _networks.NIWDenseNetwork
+    _regression_class = _regression.NegativeBinomialRegression
+
+
+class SparseNegativeBinomialGLM(_DefaultMixin, NetworkGLM):
+    _network_class = _networks.NIWSparseNetwork
+    _regression_class = _regression.SparseNegativeBinomialRegression

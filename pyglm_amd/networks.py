@@ -1,0 +1,185 @@
+"""Hierarchical priors on the (adjacency, weight) network -- host side, with the reference's class names and interface
+(pyglm/networks.py).  These touch only O(N^2 B) sufficient statistics per sweep, so they stay in NumPy; what matters for
+the hot path is that their outputs (rho, mu_W, sigma_W) are handed to the regressions without the reference's
+O(N^3 B^2) per-row rebuilds (networks.py:96-130 are re-evaluated N times at models.py:233-236).
+
+`pybasicbayes.distributions.Gaussian` (NIW) is not vendored with the reference; `_NIW` restates its published conjugate
+update and draw (PARITY UNPINNED against the third-party package, see oracle/pyglm_oracle.py).
+"""
+import numpy as np
+import scipy.linalg as sla
+
+from .utils.utils import expand_scalar, expand_cov
+
+
+def _sample_invwishart(S, nu, rng):
+    n = S.shape[0]
+    chol = np.linalg.cholesky(S)
+    if (nu <= 81 + n) and (nu == np.round(nu)):
+        x = rng.randn(int(nu), n)
+    else:
+        x = np.diag(np.sqrt(np.atleast_1d(rng.chisquare(nu - np.arange(n)))))
+        x[np.triu_indices_from(x, 1)] = rng.randn(n * (n - 1) // 2)
+    R = np.linalg.qr(x, "r")
+    T = sla.solve_triangular(R.T, chol.T, lower=True).T
+    return T.dot(T.T)
+
+
+class _NIW(object):
+    """Gaussian with a normal-inverse-Wishart prior: resample(data) draws (mu, sigma) from the posterior."""
+
+    def __init__(self, mu_0, sigma_0, kappa_0, nu_0, rng=None):
+        self.mu_0, self.sigma_0 = np.asarray(mu_0, float), np.asarray(sigma_0, float)
+        self.kappa_0, self.nu_0 = float(kappa_0), float(nu_0)
+        self.rng = np.random if rng is None else rng
+        self.resample()
+
+    def resample(self, data=()):
+        D = len(self.mu_0)
+        data = np.asarray(data, dtype=float).reshape(-1, D)
+        n = data.shape[0]
+        mu_n, sigma_n, kappa_n, nu_n = self.mu_0, self.sigma_0, self.kappa_0, self.nu_0
+        if n > 0:
+            xbar = data.mean(0)
+            centred = data - xbar
+            dev = xbar - self.mu_0
+            mu_n = (self.kappa_0 * self.mu_0 + n * xbar) / (self.kappa_0 + n)
+            sigma_n = self.sigma_0 + centred.T.dot(centred) + self.kappa_0 * n / (self.kappa_0 + n) * np.outer(dev, dev)
+            kappa_n, nu_n = self.kappa_0 + n, self.nu_0 + n
+        self.sigma = _sample_invwishart(sigma_n, nu_n, self.rng)
+        self.mu = self.rng.multivariate_normal(mu_n, self.sigma / kappa_n)
+
+
+class _NetworkModel(object):
+    """(networks.py:13-73) a prior over A in {0,1}^{NxN} and W in R^{NxNxB}; rows = postsynaptic (incoming)."""
+
+    def __init__(self, N, B, **kwargs):
+        self.N, self.B = N, B
+
+    def resample(self, data=[]):
+        assert isinstance(data, tuple)
+        A, W = data
+        assert A.shape == (self.N, self.N) and A.dtype == bool and W.shape == (self.N, self.N, self.B)
+
+    def log_likelihood(self, x):
+        return 0
+
+    def rvs(self, size=[]):
+        return None
+
+
+class _IndependentGaussianMixin(_NetworkModel):
+    """every weight ~ N(mu, Sigma) with a shared NIW prior; self-connections get their own (networks.py:76-149)"""
+
+    def __init__(self, N, B, mu_0=0.0, sigma_0=1.0, kappa_0=1.0, nu_0=3.0, is_diagonal_weight_special=True, **kwargs):
+        super(_IndependentGaussianMixin, self).__init__(N, B)
+        mu_0 = expand_scalar(mu_0, (B,))
+        sigma_0 = expand_cov(sigma_0, (B, B))
+        self._gaussian = _NIW(mu_0, sigma_0, kappa_0, max(nu_0, B + 2.))
+        self.is_diagonal_weight_special = is_diagonal_weight_special
+        if is_diagonal_weight_special:
+            # reference networks.py:94 passes the raw nu_0 (= 3), an improper inverse-Wishart for B > 3; floor it as :89 does
+            self._self_gaussian = _NIW(mu_0, sigma_0, kappa_0, max(nu_0, B + 2.))
+
+    def _rows(self, off, diag, n0, n1):
+        out = np.empty((n1 - n0, self.N) + off.shape)
+        out[:] = off
+        if diag is not None:
+            r = np.arange(n0, n1)
+            out[r - n0, r] = diag
+        return out
+
+    def mu_W_rows(self, n0, n1):
+        return self._rows(self._gaussian.mu, self._self_gaussian.mu if self.is_diagonal_weight_special else None, n0, n1)
+
+    def sigma_W_rows(self, n0, n1):
+        return self._rows(self._gaussian.sigma, self._self_gaussian.sigma if self.is_diagonal_weight_special else None, n0, n1)
+
+    @property
+    def mu_W(self):
+        return self.mu_W_rows(0, self.N)
+
+    @property
+    def sigma_W(self):
+        return self.sigma_W_rows(0, self.N)
+
+    def resample(self, data=[]):
+        super(_IndependentGaussianMixin, self).resample(data)
+        A, W = data
+        if self.is_diagonal_weight_special:
+            eye = np.eye(self.N, dtype=bool)
+            self._gaussian.resample(W[A & ~eye])
+            self._self_gaussian.resample(W[A & eye])
+        else:
+            self._gaussian.resample(W[A])
+
+
+class _FixedWeightsMixin(_NetworkModel):
+    """(networks.py:151-173)"""
+
+    def __init__(self, N, B, mu=0.0, sigma=1.0, mu_self=None, sigma_self=None, **kwargs):
+        super(_FixedWeightsMixin, self).__init__(N, B)
+        self._mu = expand_scalar(mu, (N, N, B))
+        self._sigma = expand_cov(sigma, (N, N, B, B))
+        if (mu_self is not None) and (sigma_self is not None):
+            r = np.arange(N)
+            self._mu[r, r, :] = expand_scalar(mu_self, (N, B))
+            self._sigma[r, r, :] = expand_cov(sigma_self, (N, B, B))
+
+    mu_W = property(lambda self: self._mu)
+    sigma_W = property(lambda self: self._sigma)
+
+    def mu_W_rows(self, n0, n1):
+        return self._mu[n0:n1]
+
+    def sigma_W_rows(self, n0, n1):
+        return self._sigma[n0:n1]
+
+
+class _FixedAdjacencyMixin(_NetworkModel):
+    """(networks.py:178-190)"""
+
+    def __init__(self, N, B, rho=0.5, rho_self=None, **kwargs):
+        super(_FixedAdjacencyMixin, self).__init__(N, B)
+        self._rho = expand_scalar(rho, (N, N))
+        if rho_self is not None:
+            self._rho[np.diag_indices(N)] = rho_self
+
+    rho = property(lambda self: self._rho)
+
+
+class _DenseAdjacencyMixin(_NetworkModel):
+    """(networks.py:194-204)"""
+
+    def __init__(self, N, B, **kwargs):
+        super(_DenseAdjacencyMixin, self).__init__(N, B)
+        self._rho = np.ones((N, N))
+
+    rho = property(lambda self: self._rho)
+
+
+class FixedMeanDenseNetwork(_DenseAdjacencyMixin, _FixedWeightsMixin):
+    def __init__(self, N, B, **kw):
+        _FixedWeightsMixin.__init__(self, N, B, **kw)
+        _DenseAdjacencyMixin.__init__(self, N, B, **kw)
+
+
+class FixedMeanSparseNetwork(_FixedAdjacencyMixin, _FixedWeightsMixin):
+    def __init__(self, N, B, **kw):
+        _FixedWeightsMixin.__init__(self, N, B, **kw)
+        _FixedAdjacencyMixin.__init__(self, N, B, **{k: v for k, v in kw.items() if k in ("rho", "rho_self")})
+
+
+class NIWDenseNetwork(_DenseAdjacencyMixin, _IndependentGaussianMixin):
+    def __init__(self, N, B, **kw):
+        _IndependentGaussianMixin.__init__(self, N, B, **kw)
+        _DenseAdjacencyMixin.__init__(self, N, B)
+
+
+class NIWSparseNetwork(_FixedAdjacencyMixin, _IndependentGaussianMixin):
+    """NB: in the reference the MRO drops **kwargs at networks.py:180 (every NIWSparseNetwork gets the default NIW
+    hyper-parameters and rho = 0.5 unless rho/rho_self are given); here the keyword arguments reach both mixins."""
+
+    def __init__(self, N, B, **kw):
+        _IndependentGaussianMixin.__init__(self, N, B, **{k: v for k, v in kw.items() if k not in ("rho", "rho_self")})
+        _FixedAdjacencyMixin.__init__(self, N, B, **{k: v for k, v in kw.items() if k in ("rho", "rho_self")})

@@ -1,0 +1,191 @@
+"""Per-neuron regression objects with the reference's interface (pyglm/regression.py), host state only.
+
+A regression owns its NumPy state (a, W, b) and hyper-parameters exactly like the reference's objects, so user code
+that pokes `model.regressions[n].a[n] = True` or sets `reg.S_w = ...` keeps working.  All arithmetic of the Gibbs
+path runs on the GPU: a population model batches its regressions through `pyglm_amd.engine.GibbsEngine`; a
+stand-alone regression (examples/bernoulli_regression.py style) builds a one-neuron engine on demand.
+"""
+import numpy as np
+import numpy.random as npr
+
+from .utils.utils import logistic, expand_scalar, expand_cov
+
+
+class _SparseScalarRegressionBase(object):
+    """spike-and-slab regression y_t ~ sum_n a_n w_n.x_{t,n} + b  (reference regression.py:40-92)."""
+    _obs = None
+
+    def __init__(self, N, B, rho=0.5, mu_w=0.0, S_w=1.0, mu_b=0.0, S_b=1.0):
+        self.N, self.B = N, B
+        self.rho, self.mu_w, self.mu_b, self.S_w, self.S_b = rho, mu_w, mu_b, S_w, S_b
+        # initial state: a draw from the prior, same NumPy calls as the reference (:86-92)
+        self.a = npr.rand(N) < self.rho
+        self.W = np.zeros((N, B))
+        if N <= 256:
+            for n in range(N):
+                self.W[n] = self.a[n] * npr.multivariate_normal(self.mu_w[n], self.S_w[n])
+        else:   # same law, vectorised (a million multivariate_normal calls at N = 1024 would take a minute)
+            L = np.linalg.cholesky(self.S_w)
+            self.W = self.a[:, None] * (self.mu_w + np.einsum("nij,nj->ni", L, npr.randn(N, B)))
+        self.b = npr.multivariate_normal(self.mu_b, self.S_b)
+        self._engine_cache = None
+
+    # hyper-parameter setters broadcast scalars (:95-136)
+    rho = property(lambda self: self._rho, lambda self, v: setattr(self, "_rho", expand_scalar(v, (self.N,))))
+    mu_w = property(lambda self: self._mu_w, lambda self, v: setattr(self, "_mu_w", expand_scalar(v, (self.N, self.B))))
+    mu_b = property(lambda self: self._mu_b, lambda self, v: setattr(self, "_mu_b", expand_scalar(v, (1,))))
+    S_w = property(lambda self: self._S_w, lambda self, v: setattr(self, "_S_w", expand_cov(v, (self.N, self.B, self.B))))
+
+    @property
+    def S_b(self):
+        return self._S_b
+
+    @S_b.setter
+    def S_b(self, value):
+        assert np.isscalar(value)
+        self._S_b = expand_cov(value, (1, 1))
+
+    @property
+    def natural_params(self):
+        """(:138-151)"""
+        J_w = np.linalg.inv(self.S_w)
+        h_w = np.einsum("nij,nj->ni", J_w, self.mu_w)
+        J_b = np.linalg.inv(self.S_b)
+        return J_w, h_w, J_b, J_b.dot(self.mu_b)
+
+    @property
+    def deterministic_sparsity(self):
+        return bool(np.all((self.rho < 1e-6) | (self.rho > 1 - 1e-6)))
+
+    def _flatten_X(self, X):
+        X = np.asarray(X)
+        if X.ndim == 3:
+            X = X.reshape(-1, self.N * self.B)
+        elif X.ndim != 2:
+            raise Exception
+        assert X.shape[1] == self.N * self.B
+        return X
+
+    def extract_data(self, data):
+        assert isinstance(data, tuple) and len(data) == 2
+        X, y = data
+        T = X.shape[0]
+        assert y.shape == (T, 1) or y.shape == (T,)
+        return self._flatten_X(X), y
+
+    # ---- GPU-backed stand-alone operations
+    def _engine(self, datas):
+        from .engine import GibbsEngine
+        key = tuple((id(X), id(y), X.shape[0]) for X, y in datas)
+        if self._engine_cache is None or self._engine_cache[0] != key:
+            eng = GibbsEngine(self.N, self.B, 0, 1, obs=self._obs, xi=getattr(self, "xi", 1.0), batch=1)
+            for X, y in datas:
+                X, y = self.extract_data((X, y))
+                Y = np.zeros((X.shape[0], self.N))
+                Y[:, 0] = np.asarray(y, dtype=float).ravel()
+                eng.add_data(Y, X=X.reshape(-1, self.N, self.B))
+            self._engine_cache = (key, eng)
+        return self._engine_cache[1]
+
+    def activation(self, X):
+        """psi = X.vec(a*W) + b  (:195-201)"""
+        X = self._flatten_X(X)
+        eng = self._engine([(X, np.zeros(X.shape[0]))])
+        return eng.psi(self.a[None], self.W[None], self.b)[:, 0]
+
+    def resample(self, datas, seed=None, sweep=0):
+        """One Gibbs update of (a, W, b) given datasets [(X, y), ...]  (:265-280)."""
+        from .engine import make_draws, prior_terms
+        eng = self._engine(datas)
+        seed = int(npr.randint(2 ** 31)) if seed is None else seed
+        Jw, hw, Jb, hb, c0 = prior_terms(self.S_w[None], self.mu_w[None], self.S_b.reshape(1), self.mu_b.reshape(1))
+        perm, u, z = make_draws(seed, sweep, [0], self.N, self.N * self.B)
+        a, W, b, _ = eng.sweep(self.a[None], self.W[None], self.b, self.rho[None], Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep)
+        self.a, self.W, self.b = a[0], W[0], b.reshape(1)
+
+
+class _SparsePGRegressionBase(_SparseScalarRegressionBase):
+    """count observations through Polya-gamma augmentation (reference regression.py:459-511); the observation model is
+    given by the hooks a_func/b_func/c_func (:479-489)."""
+
+    def log_likelihood(self, x):
+        """per-bin log p(y_t | psi_t) = log c + a psi - b log(1+e^psi)  (:491-494).  The per-bin vector is formed on the
+        host from the GPU activation (the population model uses the fused device reduction instead)."""
+        X, y = self.extract_data(x)
+        psi = self.activation(X)
+        return np.log(self.c_func(y)) + self.a_func(y) * psi - self.b_func(y) * np.log1p(np.exp(psi))
+
+    def kappa(self, X, y):
+        return self.a_func(y) - self.b_func(y) / 2.0
+
+
+class SparseBernoulliRegression(_SparsePGRegressionBase):
+    """a=y, b=1, c=1 (:514-522)"""
+    _obs = "bernoulli"
+
+    def a_func(self, data):
+        return data
+
+    def b_func(self, data):
+        return np.ones_like(data, dtype=float)
+
+    def c_func(self, data):
+        return 1.0
+
+    def mean(self, X):
+        return logistic(self.activation(X))
+
+    def rvs(self, X=None, size=[], psi=None):
+        if psi is None:
+            if X is None:
+                assert isinstance(size, int)
+                X = npr.randn(size, self.N * self.B)
+            p = self.mean(self._flatten_X(X))
+        else:
+            p = logistic(psi)
+        return npr.rand(*p.shape) < p
+
+
+class BernoulliRegression(SparseBernoulliRegression):
+    """dense weights: rho = 1 (:544-552)"""
+
+    def __init__(self, N, B, **kwargs):
+        kwargs["rho"] = np.ones(N)
+        super(BernoulliRegression, self).__init__(N, B, **kwargs)
+
+
+class SparseNegativeBinomialRegression(_SparsePGRegressionBase):
+    """named in the reference docstring (:463-466) but not implemented there; defined through the hooks (:479-489):
+    y ~ NB(xi, sigma(psi)):  a = y, b = y + xi, c = C(y+xi-1, y)."""
+    _obs = "negbin"
+
+    def __init__(self, N, B, xi=1.0, **kwargs):
+        assert xi > 0 and float(xi) == int(xi), "integer shape xi required (PG(b, z) is drawn as a sum of b PG(1, z))"
+        self.xi = float(xi)
+        super(SparseNegativeBinomialRegression, self).__init__(N, B, **kwargs)
+
+    def a_func(self, data):
+        return data
+
+    def b_func(self, data):
+        return data + self.xi
+
+    def c_func(self, data):
+        from scipy.special import gammaln
+        return np.exp(gammaln(data + self.xi) - gammaln(data + 1) - gammaln(self.xi))
+
+    def mean(self, X):
+        psi = self.activation(X)
+        return self.xi * np.exp(psi)
+
+    def rvs(self, X=None, size=[], psi=None):
+        if psi is None:
+            psi = self.activation(self._flatten_X(X))
+        p = logistic(psi)
+        return npr.negative_binomial(self.xi, 1 - p).astype(float)
+
+
+class NegativeBinomialRegression(SparseNegativeBinomialRegression):
+    def __init__(self, N, B, **kwargs):
+        kwargs["rho"] = np.ones(N)
+        super(NegativeBinomialRegression, self).__init__(N, B, **kwargs)
