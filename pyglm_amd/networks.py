@@ -72,7 +72,7 @@ class _IndependentGaussianMixin(_NetworkModel):
     """every weight ~ N(mu, Sigma) with a shared NIW prior; self-connections get their own (networks.py:76-149)"""
 
     def __init__(self, N, B, mu_0=0.0, sigma_0=1.0, kappa_0=1.0, nu_0=3.0, is_diagonal_weight_special=True, **kwargs):
-        super(_IndependentGaussianMixin, self).__init__(N, B)
+        _NetworkModel.__init__(self, N, B)
         mu_0 = expand_scalar(mu_0, (B,))
         sigma_0 = expand_cov(sigma_0, (B, B))
         self._gaussian = _NIW(mu_0, sigma_0, kappa_0, max(nu_0, B + 2.))
@@ -118,7 +118,7 @@ class _FixedWeightsMixin(_NetworkModel):
     """(networks.py:151-173)"""
 
     def __init__(self, N, B, mu=0.0, sigma=1.0, mu_self=None, sigma_self=None, **kwargs):
-        super(_FixedWeightsMixin, self).__init__(N, B)
+        _NetworkModel.__init__(self, N, B)
         self._mu = expand_scalar(mu, (N, N, B))
         self._sigma = expand_cov(sigma, (N, N, B, B))
         if (mu_self is not None) and (sigma_self is not None):
@@ -140,7 +140,7 @@ class _FixedAdjacencyMixin(_NetworkModel):
     """(networks.py:178-190)"""
 
     def __init__(self, N, B, rho=0.5, rho_self=None, **kwargs):
-        super(_FixedAdjacencyMixin, self).__init__(N, B)
+        _NetworkModel.__init__(self, N, B)
         self._rho = expand_scalar(rho, (N, N))
         if rho_self is not None:
             self._rho[np.diag_indices(N)] = rho_self
@@ -152,7 +152,7 @@ class _DenseAdjacencyMixin(_NetworkModel):
     """(networks.py:194-204)"""
 
     def __init__(self, N, B, **kwargs):
-        super(_DenseAdjacencyMixin, self).__init__(N, B)
+        _NetworkModel.__init__(self, N, B)
         self._rho = np.ones((N, N))
 
     rho = property(lambda self: self._rho)
