@@ -1,0 +1,169 @@
+"""GPU tests of the drop-in API: the reference's own tests (test/test_generate.py) re-expressed on pyglm_amd, the flows of
+examples/synthetic.py and examples/bernoulli_regression.py, a sweep-by-sweep replay of the population model against the
+oracle, and the negative-binomial observation model."""
+import numpy as np
+import pytest
+
+from oracle import pyglm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generate_lags_reference_test_basis():
+    # reference test/test_generate.py:42-55
+    from pyglm_amd.regression import SparseBernoulliRegression
+    from pyglm_amd.models import NonlinearAutoregressiveModel
+    np.random.seed(0)
+    N, B = 2, 3
+    regs = [SparseBernoulliRegression(N, B, mu_b=-2, S_b=0.1) for _ in range(N)]
+    model = NonlinearAutoregressiveModel(N, regs, B=B)
+    X, Y = model.generate(T=1000, keep=False)
+    for n in range(N):
+        for b in range(B):
+            assert np.allclose(Y[:-(b + 1), n], X[(b + 1):, n, b])
+
+
+def test_generate_means_reference_test_means():
+    # reference test/test_generate.py:10-39
+    from pyglm_amd.regression import SparseBernoulliRegression
+    from pyglm_amd.models import NonlinearAutoregressiveModel
+    from pyglm_amd.utils.basis import cosine_basis
+    np.random.seed(1)
+    N, B, L = 2, 3, 10
+    basis = cosine_basis(B, L=L) / L
+    regs = [SparseBernoulliRegression(N, B, mu_b=-2, S_b=0.1) for _ in range(N)]
+    model = NonlinearAutoregressiveModel(N, regs, basis=basis)
+    X, Y = model.generate(T=1000, keep=False)
+    model.add_data(Y)
+    Xtest = np.asarray(model.data_list[0][0])
+    assert np.allclose(X, Xtest)
+    means = model.means
+    model2 = NonlinearAutoregressiveModel(N, regs, basis=basis)
+    model2.add_data(Y, X=X)
+    assert np.allclose(means[0], model2.means[0])
+    # and against the oracle's closed form
+    want = np.column_stack([orc.logistic(X.reshape(1000, -1) @ (r.a[:, None] * r.W).ravel() + r.b[0]) for r in regs])
+    np.testing.assert_allclose(means[0], want, rtol=1e-10)
+
+
+def test_model_sweeps_replay_against_oracle():
+    """three full resample_model() sweeps (regressions + network prior push); every sweep is replayed on the CPU with the
+    oracle from the same pre-sweep state, hyper-parameters, random inputs and the GPU's own omega."""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.engine import make_draws
+    from pyglm_amd.utils.basis import cosine_basis
+    np.random.seed(3)
+    N, B, T = 6, 2, 1500
+    basis = cosine_basis(B, L=20) / 20
+    true = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=1)
+    for n in range(N):
+        true.regressions[n].a[n] = True
+        true.regressions[n].W[n, :] = -2.0
+    _, Y = true.generate(T=T, keep=False)
+    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=17)
+    model.add_data(Y)
+    X = np.asarray(model.data_list[0][0])
+    for sweep in range(3):
+        pre = [(r.a.copy(), r.W.copy(), r.b.copy(), r.rho.copy(), r.mu_w.copy(), r.S_w.copy(), r.mu_b.copy(), r.S_b.copy()) for r in model.regressions]
+        ll_pre = model.log_likelihood()
+        model.resample_model()
+        om = model.engine.datasets[0].OK[:T, :N].cpu().numpy()
+        perm, u, z = make_draws(17, sweep, range(N), N, N * B)
+        ll_want = 0.0
+        for n, (a, W, b, rho, mu_w, S_w, mu_b, S_b) in enumerate(pre):
+            r = orc.Regression(N, B, rho=rho, mu_w=mu_w, S_w=S_w, mu_b=mu_b, S_b=S_b)
+            r.a, r.W, r.b = a, W, b
+            ll_want += r.log_likelihood(X, Y[:, n]).sum()
+            r.resample([(X, Y[:, n])], [om[:, n]], perm[n], u[n], z[n])
+            np.testing.assert_array_equal(model.regressions[n].a, r.a)
+            np.testing.assert_allclose(model.regressions[n].W, r.W, rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(model.regressions[n].b, r.b, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(ll_pre, ll_want, rtol=1e-10)
+        # network push (models.py:233-236): rows = postsynaptic
+        assert model.regressions[2].S_w.shape == (N, B, B)
+        np.testing.assert_array_equal(model.regressions[2].mu_w[2], model.network._self_gaussian.mu)
+        np.testing.assert_array_equal(model.regressions[2].mu_w[3], model.network._gaussian.mu)
+    assert model.weights.shape == (N, N, B) and model.adjacency.shape == (N, N) and model.biases.shape == (N,)
+
+
+def test_synthetic_example_flow_recovers_self_inhibition():
+    """examples/synthetic.py:17-84 at its own size (N=4, B=1, L=100, T=10000 = BASELINE.json configs[0])"""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.utils.basis import cosine_basis
+    np.random.seed(0)
+    T, N, B, L = 10000, 4, 1, 100
+    basis = cosine_basis(B=B, L=L) / L
+    true_model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.), seed=3)
+    for n in range(N):
+        true_model.regressions[n].a[:] = False
+        true_model.regressions[n].W[:] = 0
+        true_model.regressions[n].a[n] = True
+        true_model.regressions[n].W[n, :] = -2.0
+        true_model.regressions[n].b[:] = -1.0
+    _, Y = true_model.generate(T=T, keep=True)
+    ll_true = true_model.log_likelihood()
+    test_model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.), seed=4)
+    test_model.add_data(Y)
+    lps, As, Ws = [], [], []
+    for itr in range(40):
+        test_model.resample_model()
+        lps.append(test_model.log_likelihood())
+        As.append(test_model.adjacency.copy())
+        Ws.append(test_model.weights.copy())
+    A_mean = np.mean(As[20:], axis=0)
+    W_mean = np.mean(Ws[20:], axis=0)
+    assert np.all(np.diag(A_mean) > 0.9), A_mean
+    assert np.all(np.diag(W_mean[:, :, 0]) < -1.0), W_mean[:, :, 0]
+    assert np.mean(lps[20:]) > ll_true - 30          # the fitted chain explains the data as well as the truth does
+    assert np.mean(lps[20:]) > lps[0] - 1.0
+
+
+def test_standalone_regression_flow():
+    """examples/bernoulli_regression.py:12-39: start from the complement adjacency, the chain finds the true one"""
+    from pyglm_amd.regression import SparseBernoulliRegression
+    np.random.seed(2)
+    N, B, T = 2, 1, 1000
+    true_reg = SparseBernoulliRegression(N, B)
+    true_reg.a[:] = [True, False]
+    true_reg.W[:] = [[2.5], [0.0]]
+    X = np.random.randn(T, N * B)
+    y = true_reg.rvs(X=X)
+    test_reg = SparseBernoulliRegression(N, B)
+    test_reg.a = np.bitwise_not(true_reg.a)
+    As = []
+    for i in range(60):
+        test_reg.resample([(X, y)], seed=5, sweep=i)
+        As.append(test_reg.a.copy())
+    A_mean = np.mean(As[20:], axis=0)
+    assert A_mean[0] > 0.9 and A_mean[1] < 0.5, A_mean
+    ll = test_reg.log_likelihood((X, y))
+    assert ll.shape == (T,) and np.all(np.isfinite(ll))
+
+
+def test_negative_binomial_sweep_vs_oracle():
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    rng = np.random.default_rng(4)
+    N, B, T, xi = 10, 2, 900, 3.0
+    basis = orc.cosine_basis(B, L=15) / 15
+    Y = rng.negative_binomial(xi, 0.8, size=(T, N)).astype(float)
+    X = orc.convolve_with_basis(Y, basis)
+    kw = dict(rho=0.5, S_w=2.0, mu_w=0.0, mu_b=-1.0, S_b=1.0)
+    a = rng.random((N, N)) < 0.3
+    W = rng.standard_normal((N, N, B)) * 0.2 * a[:, :, None]
+    b = np.full(N, -1.5)
+    eng = GibbsEngine(N, B, obs="negbin", xi=xi)
+    eng.add_data(Y, X=X)
+    regs = [orc.Regression(N, B, obs="negbin", xi=xi, **kw) for _ in range(N)]
+    hyp = prior_terms(np.array([r.S_w for r in regs]), np.array([r.mu_w for r in regs]), np.ones(N), np.full(N, -1.0))
+    perm, u, z = make_draws(8, 0, range(N), N, N * B)
+    a1, W1, b1, ll = eng.sweep(a, W, b, np.full((N, N), 0.5), *hyp, perm, u, z, seed=8, sweep=0)
+    om = eng.datasets[0].OK[:T, :N].cpu().numpy()
+    for n, r in enumerate(regs):
+        r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+        np.testing.assert_allclose(ll[n], r.log_likelihood(X, Y[:, n]).sum(), rtol=1e-10)
+        want = orc.pg_draw(Y[:, n] + xi, r.activation(X), 8, orc.stream_id(n, 0))      # PG(y + xi, psi), regression.py:479-489
+        assert (np.abs(om[:, n] - want) <= 1e-12 * want).mean() >= 1 - 5e-3
+        r.resample([(X, Y[:, n])], [om[:, n]], perm[n], u[n], z[n])
+        np.testing.assert_array_equal(a1[n], r.a)
+        np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(b1[n], r.b[0], rtol=1e-7, atol=1e-9)
