@@ -137,9 +137,11 @@ def main():
     if rank == 0:
         g = stages.get("gram", dict(ms=0.0, calls=0, work=0.0))
         achieved = (g["work"] / (g["ms"] * 1e-3) * 1e-12) if g["ms"] > 0 else None
+        # HBM bytes per Gram launch from the committed rocprofv3 --pmc passes (profiles/gram_pmc.json); only valid for the
+        # workload and launch geometry they were collected on (cfg3, one GPU)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "gram_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.config == "cfg3" and world == 1 and (N, B, T) == (1024, 5, 100000):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:

@@ -17,20 +17,21 @@
 //   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the 32
 //     workgroups resident on one XCD share the same X panels through that XCD's L2.
 #include "pgl_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int BK = 16;
 constexpr int PAD = 16;
 
-template <int WM, int WN, int WZ, bool WEIGHTED>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2>
 struct Cfg {
     static constexpr int BM = WM * 64, BN = WN * 64;
     static constexpr int SA = BM + PAD, SB = BN + PAD;
     static constexpr int THREADS = WM * WN * WZ * 64;
     static constexpr int A_ELEMS = BK * SA, B_ELEMS = BK * SB, W_ELEMS = WEIGHTED ? BK * WZ : 0;
     static constexpr int STAGE = A_ELEMS + B_ELEMS + W_ELEMS;
-    static constexpr size_t LDS_BYTES = 2ull * STAGE * sizeof(double);
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * sizeof(double);
     // 16-byte loads per thread per K-tile
     static constexpr int A_LD = (BK * BM / 2) / THREADS, B_LD = (BK * BN / 2) / THREADS;
     static_assert((BK * BM / 2) % THREADS == 0 && (BK * BN / 2) % THREADS == 0, "tile/threads mismatch");
@@ -44,9 +45,16 @@ __device__ __forceinline__ int isqrt_tri(int t) {
     return r;
 }
 
-template <int WM, int WN, int WZ, bool WEIGHTED>
+// wave-level LDS hand-off without draining global loads that are still in flight (a plain __syncthreads() may)
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
 __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g) {
-    using C = Cfg<WM, WN, WZ, WEIGHTED>;
+    using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     // ---- work decode (XCD-aware: consecutive slots on one XCD walk the batch / M-tile index)
@@ -54,7 +62,8 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     const int ntiles = g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn;
     const long total = (long)ntiles * g.nbatch;
     const long chunk = (total + 7) / 8;
-    const long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (g.debug & 16) w = blockIdx.x;                   // experiment: every XCD walks the same tile (MALL-served panels)
     if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
     int tile, batch, tm, tn;
     if (g.nbatch > 1) { tile = (int)(w / g.nbatch); batch = (int)(w % g.nbatch); }
@@ -122,37 +131,104 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
     const int frow = lane >> 4, fcol = lane & 15;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+    auto compute = [&](int buf, int kk) {
         const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
         const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
         const double* Ws = smem + buf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
+        const int kr = kk * 4 + frow;
+        double a[4], b[4];
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int kr = kk * 4 + frow;
-            double a[4], b[4];
+        for (int i = 0; i < 4; ++i) a[i] = As[kr * C::SA + i * 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kr * C::SA + i * 16];
+        for (int j = 0; j < 4; ++j) b[j] = Bs[kr * C::SB + j * 16];
+        if (WEIGHTED && !(g.debug & 2)) {
+            const double wv = Ws[kr * WZ + wz];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[kr * C::SB + j * 16];
-            if (WEIGHTED) {
-                const double wv = Ws[kr * WZ + wz];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] *= wv;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) a[i] *= wv;
         }
-        if (kt + 1 < nkt) lstore(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+
+    if constexpr (STAGES == 2) {
+        // two LDS stages, one barrier at the end of every K tile
+        gload(0);
+        lstore(0);
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = (g.debug & 1) ? 0 : (kt & 1);
+            if (kt + 1 < nkt && !(g.debug & 1)) gload(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
+            if (kt + 1 < nkt && !(g.debug & 1)) lstore(buf ^ 1);
+            if (!(g.debug & 4)) __syncthreads();
+        }
+    } else {
+        // three LDS stages, the barrier sits in the MIDDLE of a K tile: tile kt+1 is written to LDS (from registers loaded a
+        // whole tile earlier) after the first half of tile kt's MFMAs, every wave passes the barrier, the second half runs.
+        // Stage (kt+1)%3 was last read in tile kt-2, which every wave had finished before it could pass the barrier of
+        // tile kt-1.  Because tile kt+1 is readable from the middle of tile kt on, the fragment pipeline never drains:
+        // the raw fragments of k-step s+1 are fetched from LDS before the 16 MFMAs of step s are issued and are scaled by
+        // omega after the first 8 of them, so neither the ds_read latency nor the v_mul_f64 -> MFMA dependency is exposed
+        // (f64 VALU shares the MFMA pipe: only the multiplies' own ~4.5 cycles each remain).
+        gload(0);
+        lstore(0);
+        if (nkt > 1) gload(1);
+        __syncthreads();
+        double fa[2][4] = {{1, 2, 3, 4}, {5, 6, 7, 8}}, fb[2][4] = {{1, 2, 3, 4}, {5, 6, 7, 8}}, fw[2] = {1, 1};
+        auto fetch = [&](int buf, int kk, int set) {
+            const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
+            const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
+            const double* Ws = smem + buf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
+            const int kr = kk * 4 + frow;
+            if (g.debug & 8) return;                    // ablation: no fragment traffic at all (MFMA-only loop)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[set][i] = As[kr * C::SA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[set][j] = Bs[kr * C::SB + j * 16];
+            fw[set] = WEIGHTED ? Ws[kr * WZ + wz] : 1.0;
+        };
+        auto scale = [&](int set) {
+            if (WEIGHTED && !(g.debug & 2)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[set][i] *= fw[set];
+            }
+        };
+        auto mma_half = [&](int set, int h) {
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+        };
+        int cur = 0;
+        fetch(0, 0, 0);
+        scale(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int nxt = (g.debug & 1) ? 0 : ((cur == 2) ? 0 : cur + 1);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                const int set = kk & 1;
+                if (kk + 1 < BK / 4) fetch(cur, kk + 1, set ^ 1);
+                else fetch(nxt, 0, set ^ 1);            // published by this tile's mid barrier (stale only after the last tile)
+                __builtin_amdgcn_sched_barrier(0);      // keep the ds_reads ahead of the MFMAs (hipcc sinks them otherwise)
+                mma_half(set, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                scale(set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(set, 1);
+                if (kk == BK / 8 - 1) {
+                    if (kt + 1 < nkt && !(g.debug & 1)) {
+                        lstore(nxt);
+                        if (kt + 2 < nkt) gload(kt + 2);
+                    }
+                    if (!(g.debug & 4)) block_sync_lds();
+                }
+            }
+            if (!(g.debug & 1)) cur = nxt;
+        }
     }
 
     // ---- epilogue.  f64 C/D fragment: row = (lane>>4) + 4*reg, col = lane&15 (verified on hardware)
@@ -161,6 +237,18 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        double cv[4][4];
+        if (beta != 0.0) {   // all 16 read-modify-write loads of this row block in flight before the first use
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + frow + 4 * r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wn * 64 + j * 16 + fcol;
+                    cv[r][j] = (row < Mv && col < Nv) ? Cb[(long)row * g.ldc + col] : 0.0;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * 64 + i * 16 + frow + 4 * r;
@@ -169,20 +257,19 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + fcol;
                 if (col >= Nv) continue;
-                double* p = Cb + (long)row * g.ldc + col;
                 double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * *p;
-                *p = v;
+                if (beta != 0.0) v += beta * cv[r][j];
+                Cb[(long)row * g.ldc + col] = v;
             }
         }
     }
 }
 
-template <int WM, int WN, int WZ, bool WEIGHTED>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2>
 int launch(const PglGemmArgs& a, hipStream_t st) {
-    using C = Cfg<WM, WN, WZ, WEIGHTED>;
+    using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     static bool attr_set = false;
-    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED>;
+    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED, STAGES>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", C::LDS_BYTES, hipGetErrorString(e)); return PGL_ERR_HIP; }
@@ -207,7 +294,13 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
     PGL_CHECK_ARG(a.a_cols % 2 == 0 && a.b_cols % 2 == 0 && a.lda % 2 == 0 && a.ldb % 2 == 0);
     PGL_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0);
     switch (kind) {
-        case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); return launch<2, 2, 2, true>(a, st);
+        case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); {
+            static const int variant = getenv("PGL_GRAM_STAGES") ? atoi(getenv("PGL_GRAM_STAGES")) : 3;
+            static const int dbg = getenv("PGL_GRAM_ABLATE") ? atoi(getenv("PGL_GRAM_ABLATE")) : 0;
+            PglGemmArgs b = a;
+            b.debug = dbg;
+            return variant == 2 ? launch<2, 2, 2, true, 2>(b, st) : launch<2, 2, 2, true, 3>(b, st);
+        }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
         case PGL_GEMM_TRI1: PGL_CHECK_ARG(a.M == a.N); return launch<2, 2, 1, false>(a, st);
     }
