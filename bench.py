@@ -97,7 +97,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world)
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("PGL_FORCE_DIST"))   # PGL_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from pyglm_amd.models import SparseBernoulliGLM
@@ -112,7 +115,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -128,7 +131,7 @@ def main():
     dt = time.perf_counter() - t0
     stages = model.engine.collect_timings()
     model.engine.profile = False
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -164,7 +167,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -42,6 +42,7 @@ struct PglGemmArgs {
     double alpha, beta;
     int tri;                                   // 0: all tiles; 1: tiles tm >= tn (lower); 2: tiles tm <= tn (upper)
     const int* batch_k;                        // optional per-batch K (multiple of 16; 0 = skip batch)
+    int* sched;                                // persistent launch: 8 per-XCD work counters, zeroed before the launch
     int debug;                                 // ablation switches for tools/probe_gram.py (0 in production)
     const int* batch_dim; int dim_off;         // optional per-batch square size: M = N = max(0, batch_dim[b] - dim_off)
 };

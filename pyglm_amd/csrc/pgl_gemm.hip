@@ -52,19 +52,11 @@ __device__ __forceinline__ void block_sync_lds() {
     asm volatile("" ::: "memory");
 }
 
+// one work item = one output tile of one batch (weighted mode: of one group of WZ weight columns)
 template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
-__global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g) {
+__device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, double* smem) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-
-    // ---- work decode (XCD-aware: consecutive slots on one XCD walk the batch / M-tile index)
-    const int ntm = (g.M + C::BM - 1) / C::BM, ntn = (g.N + C::BN - 1) / C::BN;
-    const int ntiles = g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn;
-    const long total = (long)ntiles * g.nbatch;
-    const long chunk = (total + 7) / 8;
-    long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (g.debug & 16) w = blockIdx.x;                   // experiment: every XCD walks the same tile (MALL-served panels)
-    if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
+    const int ntm = (g.M + C::BM - 1) / C::BM;
     int tile, batch, tm, tn;
     if (g.nbatch > 1) { tile = (int)(w / g.nbatch); batch = (int)(w % g.nbatch); }
     else { tile = (int)w; batch = 0; }
@@ -265,6 +257,64 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     }
 }
 
+// ---- plain launch: one workgroup per work item, XCD-aware order (block b runs on XCD b % 8: consecutive slots of one XCD
+// walk the batch index of the same tile, so co-resident workgroups share operand panels through that XCD's L2)
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+__global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g) {
+    using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ntm = (g.M + C::BM - 1) / C::BM, ntn = (g.N + C::BN - 1) / C::BN;
+    const long total = (long)(g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn) * g.nbatch;
+    const long chunk = (total + 7) / 8;
+    long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (g.debug & 16) w = blockIdx.x;
+    if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
+    gemm_item<WM, WN, WZ, WEIGHTED, STAGES>(g, w, smem);
+}
+
+// ---- persistent launch (long launches: the hardware dispatcher's round-robin drifts after a few hundred rounds and the
+// co-residency above is lost -- measured 1.5x panel reuse instead of ~30x at cfg3).  One workgroup per CU; each reads the
+// XCC it runs on and pulls consecutive items of that XCD's chunk from a counter, stealing from the next XCD when its own
+// chunk is exhausted.  Placement is used for speed only: any placement gives the same result.
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+__global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64_persistent(PglGemmArgs g) {
+    using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    long* ticket = reinterpret_cast<long*>(smem + (size_t)STAGES * C::STAGE);
+    const int ntm = (g.M + C::BM - 1) / C::BM, ntn = (g.N + C::BN - 1) / C::BN;
+    const long total = (long)(g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn) * g.nbatch;
+    const long chunk = (total + 7) / 8;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long w = -1;
+            for (int hop = 0; hop < 8 && w < 0; ++hop) {
+                const int y = (int)((xcc + hop) & 7u);
+                const long lo = (long)y * chunk, hi = (lo + chunk < total) ? lo + chunk : total;
+                if (lo >= hi) continue;
+                const long it = atomicAdd(&g.sched[y], 1);
+                if (lo + it < hi) w = lo + it;
+            }
+            ticket[0] = w;
+        }
+        __syncthreads();
+        const long w = ticket[0];
+        if (w < 0) break;
+        // Stagger co-resident workgroups: requests for a line that is still in flight are not merged by the L2, so 32
+        // workgroups in perfect lockstep each fetch every panel line from the fabric.  A per-rank delay of a few
+        // microseconds (once per 25 ms work item) turns 31 of them into L2 hits.
+        {
+            const int rank = (int)(w & 31);
+            const int unit = g.debug >> 8;                  // s_sleep units (64 cycles) per rank
+            for (int r = 0; r < rank * unit; r += 64) __builtin_amdgcn_s_sleep(64);
+        }
+        gemm_item<WM, WN, WZ, WEIGHTED, STAGES>(g, w, smem);
+    }
+}
+
 template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2>
 int launch(const PglGemmArgs& a, hipStream_t st) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
@@ -287,6 +337,49 @@ int launch(const PglGemmArgs& a, hipStream_t st) {
     return PGL_OK;
 }
 
+// scheduler scratch of the persistent launches: a ring of 8-counter slots (32 B each), allocated once on first use.
+// (The only device memory the library itself owns; every data buffer belongs to the caller.)
+static int* sched_slot(hipStream_t st) {
+    static int* base = nullptr;
+    static unsigned next = 0;
+    constexpr unsigned SLOTS = 256;
+    if (!base) {
+        if (hipMalloc(reinterpret_cast<void**>(&base), SLOTS * 8 * sizeof(int)) != hipSuccess) { base = nullptr; return nullptr; }
+    }
+    int* slot = base + (size_t)(next++ % SLOTS) * 8;
+    if (hipMemsetAsync(slot, 0, 8 * sizeof(int), st) != hipSuccess) return nullptr;
+    return slot;
+}
+
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+int launch_persistent(const PglGemmArgs& a0, hipStream_t st) {
+    using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    auto kern = gemm_tn_f64_persistent<WM, WN, WZ, WEIGHTED, STAGES>;
+    constexpr size_t lds = C::LDS_BYTES + 16;     // + the work ticket
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return PGL_ERR_HIP; }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n_cu <= 0) n_cu = 256;
+        attr_set = true;
+    }
+    const int ntm = (a0.M + C::BM - 1) / C::BM, ntn = (a0.N + C::BN - 1) / C::BN;
+    const long total = (a0.tri ? (long)ntm * (ntm + 1) / 2 : (long)ntm * ntn) * a0.nbatch;
+    if (total <= 0) return PGL_OK;
+    PglGemmArgs a = a0;
+    a.sched = sched_slot(st);
+    if (!a.sched) { pgl_set_error("persistent gemm: scheduler scratch unavailable"); return PGL_ERR_HIP; }
+    const long per_cu = (lds * 2 <= 160 * 1024) ? 2 : 1;
+    const long grid = total < n_cu * per_cu ? total : n_cu * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::THREADS), lds, st, a);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
 }  // namespace
 
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
@@ -296,10 +389,13 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
     switch (kind) {
         case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); {
             static const int variant = getenv("PGL_GRAM_STAGES") ? atoi(getenv("PGL_GRAM_STAGES")) : 3;
-            static const int dbg = getenv("PGL_GRAM_ABLATE") ? atoi(getenv("PGL_GRAM_ABLATE")) : 0;
+            static const int dbg = (getenv("PGL_GRAM_ABLATE") ? atoi(getenv("PGL_GRAM_ABLATE")) : 0) |
+                                   ((getenv("PGL_GRAM_STAGGER") ? atoi(getenv("PGL_GRAM_STAGGER")) : 0) << 8);
             PglGemmArgs b = a;
             b.debug = dbg;
-            return variant == 2 ? launch<2, 2, 2, true, 2>(b, st) : launch<2, 2, 2, true, 3>(b, st);
+            static const int persist = getenv("PGL_GRAM_PERSIST") ? atoi(getenv("PGL_GRAM_PERSIST")) : 1;
+            if (variant == 2) return launch<2, 2, 2, true, 2>(b, st);
+            return persist ? launch_persistent<2, 2, 2, true, 3>(b, st) : launch<2, 2, 2, true, 3>(b, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
         case PGL_GEMM_TRI1: PGL_CHECK_ARG(a.M == a.N); return launch<2, 2, 1, false>(a, st);

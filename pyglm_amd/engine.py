@@ -87,6 +87,7 @@ class GibbsEngine(object):
         if not design_only:
             self._alloc_batch()
         self.timings = {}
+        self.overlap = False     # two-stream Gram/post overlap: functional, but CU time is the shared resource -> no gain yet
         self.profile = False
         self._ev = []
 
@@ -122,7 +123,8 @@ class GibbsEngine(object):
 
     def _alloc_batch(self):
         nb, ldj, N, D, kmax = self.nb, self.ldj, self.N, self.D, self.kmax
-        self.Jbuf = self._z(nb, ldj, ldj)
+        self.Jslots = self._z(1, nb, ldj, ldj)      # one slot; a second one is only needed for the (disabled) two-stream overlap
+        self.Jbuf = self.Jslots[0]
         self.Mtab = self._z(nb, ldj, ldj)
         self.Ac = self._z(nb, ldj, ldj)
         self.hc = self._z(2, nb, ldj)
@@ -255,9 +257,46 @@ class GibbsEngine(object):
             arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
             dev[k] = torch.from_numpy(arr).to(self.dev)
         skip = torch.from_numpy(det.astype(np.int32)).to(self.dev)
-        for s in range(0, nloc, self.nb):
-            nbb = min(self.nb, nloc - s)
-            self._batch(s, nbb, a, det, dev, skip, st)
+        # Batches are software-pipelined over two HIP streams: the Gram of batch k+1 (fp64-MFMA-bound) runs on `sG` while
+        # the tableau flips and the weight draw of batch k (HBM-bound rank-k updates) run on the higher-priority `sF`.
+        batches = [(s, min(self.nb, nloc - s)) for s in range(0, nloc, self.nb)]
+        main = torch.cuda.current_stream(self.dev)
+        if self.overlap and len(batches) > 1 and self.Jslots.shape[0] > 1:
+            if not hasattr(self, "_sG"):
+                self._sG = torch.cuda.Stream(self.dev)
+                self._sF = torch.cuda.Stream(self.dev, priority=-1)
+            sG, sF = self._sG, self._sF
+            ready = torch.cuda.Event()
+            ready.record(main)
+            sG.wait_event(ready)
+            sF.wait_event(ready)
+            gram_done = [torch.cuda.Event() for _ in batches]
+            slot_free = [None, None]
+            for k, (s, nbb) in enumerate(batches):
+                slot = k & 1
+                with torch.cuda.stream(sG):
+                    if slot_free[slot] is not None:
+                        sG.wait_event(slot_free[slot])
+                    self._gram(s, nbb, slot)
+                    gram_done[k].record(sG)
+                if k >= 1:
+                    ps, pn = batches[k - 1]
+                    with torch.cuda.stream(sF):
+                        sF.wait_event(gram_done[k - 1])
+                        self._post(ps, pn, (k - 1) & 1, a, det, dev, skip)
+                        slot_free[(k - 1) & 1] = torch.cuda.Event()
+                        slot_free[(k - 1) & 1].record(sF)
+            ps, pn = batches[-1]
+            with torch.cuda.stream(sF):
+                sF.wait_event(gram_done[-1])
+                self._post(ps, pn, (len(batches) - 1) & 1, a, det, dev, skip)
+                fin = torch.cuda.Event()
+                fin.record(sF)
+            main.wait_event(fin)
+        else:
+            for (s, nbb) in batches:
+                self._gram(s, nbb, 0)
+                self._post(s, nbb, 0, a, det, dev, skip)
         torch.cuda.synchronize(self.dev)
         status = self.status.cpu().numpy()
         if status.any():
@@ -269,16 +308,26 @@ class GibbsEngine(object):
         b_new = self.b_dev.cpu().numpy().copy()
         return a_new, W_new, b_new, ll_before
 
-    def _batch(self, s, nbb, a_host, det, dev, skip, st):
-        N, B, D, ldn, Dp, ldj, kmax = self.N, self.B, self.D, self.ldn, self.Dp, self.ldj, self.kmax
-        strideJ = ldj * ldj
-        off8 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 8 * int(elems))
-        off4 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
-        # ---- omega-weighted Gram (regression.py:251-252)
+    def _gram(self, s, nbb, slot):
+        """omega-weighted Gram of local neurons [s, s+nbb) into J slot `slot` (regression.py:251-252)"""
+        D, ldn, Dp, ldj = self.D, self.ldn, self.Dp, self.ldj
+        st = self._st()
+        J = self.Jslots[slot]
         for i, ds in enumerate(self.datasets):
             h = self._tic("gram", float(nbb) * ds.T * D * (D + 1))     # algorithmic flops: lower triangle, 2 flop per MAC
-            call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, off8(ds.OK, s), 2 * ldn, ds.Tp, D, nbb, ptr(self.Jbuf), ldj, strideJ, int(i > 0), st)
+            call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * s), 2 * ldn, ds.Tp, D, nbb, ptr(J), ldj,
+                 ldj * ldj, int(i > 0), st)
             self._toc(h)
+
+    def _post(self, s, nbb, slot, a_host, det, dev, skip):
+        """posterior assembly, collapsed flips and weight draw of local neurons [s, s+nbb) from J slot `slot`"""
+        N, B, D, ldn, Dp, ldj, kmax = self.N, self.B, self.D, self.ldn, self.Dp, self.ldj, self.kmax
+        strideJ = ldj * ldj
+        st = self._st()
+        Jb_ = self.Jslots[slot]
+        self.Jbuf = Jb_
+        off8 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 8 * int(elems))
+        off4 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
         # ---- posterior assembly (regression.py:210-223, 253-260, 270-271)
         call("pgl_assemble_posterior", ptr(self.Jbuf), ldj, strideJ, off8(self.border, s * Dp), off8(self.border, (ldn + s) * Dp), Dp,
              off8(dev["Jw"], s * N * B * B), off8(dev["hw"], s * N * B), off8(dev["Jb"], s), off8(dev["hb"], s), nbb, N, B, st)

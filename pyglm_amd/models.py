@@ -118,7 +118,7 @@ class NonlinearAutoregressiveModel(object):
     def _gather_rows(self, arr):
         """all_gather of per-neuron rows over the shard axis (ranks may own different counts)"""
         dist = _dist()
-        if dist is None or self.world == 1:
+        if dist is None:
             return arr
         import torch
         nccl = dist.get_backend() == "nccl"
@@ -149,7 +149,7 @@ class NonlinearAutoregressiveModel(object):
         a, W, b = self._local_state()
         ll = float(np.sum(eng.log_likelihood(a, W, b)))
         dist = _dist()
-        if dist is not None and self.world > 1:
+        if dist is not None:
             import torch
             t = torch.tensor([ll], dtype=torch.float64)
             if dist.get_backend() == "nccl":

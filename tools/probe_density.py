@@ -13,10 +13,12 @@ model.add_data(Y)
 model.engine.profile = True
 print("init density %.3f" % model.adjacency.mean())
 for s in range(nsweep):
+    A_old = model.adjacency.copy()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     model.resample_model()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     A = model.adjacency
     st = model.engine.collect_timings()
-    print("sweep %d: %.3f s  density %.4f  max row %d  rows>10: %d | %s" % (s, dt, A.mean(), A.sum(1).max(), (A.sum(1) > 10).sum(),
+    fl = (A != A_old).sum(1)
+    print("sweep %d: %.3f s  density %.4f  max row %d  flips/row mean %.1f max %d | %s" % (s, dt, A.mean(), A.sum(1).max(), fl.mean(), fl.max(),
           " ".join("%s=%.0fms" % (k, v["ms"]) for k, v in st.items())), flush=True)
