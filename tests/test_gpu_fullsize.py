@@ -1,0 +1,135 @@
+"""Full-size GPU checks through size-independent properties (the oracle cannot finish these sizes in seconds):
+BASELINE.json configs[1] (N=128, B=5, T=50000) end to end, configs[2]-shaped (D=5120, T=100000) per-kernel identities,
+and a maximum-size dense case (D=16384) for the Cholesky path."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(N, B, T, L=100, seed=0):
+    from pyglm_amd.utils.basis import cosine_basis
+    rng = np.random.default_rng(seed)
+    basis = cosine_basis(B, L=L) / L
+    Y = (rng.random((T, N)) < 0.08).astype(np.float64)
+    return basis, Y, rng
+
+
+def test_gram_identities_at_cfg3_shape():
+    """D=5120, T=100000 (configs[2]); for a handful of neurons:
+    linearity  J(w1 + 2 w2) = J(w1) + 2 J(w2);  trace identity  tr J = sum_t w_t |x_t|^2;  J(1)[i][j] = (X'X)[i][j] on a torch
+    fp64 reference for a band of columns;  symmetry of diagonal tiles; the border contraction against torch."""
+    import torch
+    from pyglm_amd.engine import GibbsEngine
+    from pyglm_amd._lib import call, ptr
+    N, B, T = 1024, 5, 100000
+    basis, Y, rng = _problem(N, B, T)
+    eng = GibbsEngine(N, B, 0, 4, batch=4)
+    ds = eng.add_data(Y, basis=basis)
+    D, Dp, ldj = eng.D, eng.Dp, eng.ldj
+    W = torch.zeros(ds.Tp, 4, dtype=torch.float64, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    W[:T, 0] = torch.rand(T, generator=g, device="cuda", dtype=torch.float64) * 0.25
+    W[:T, 1] = torch.rand(T, generator=g, device="cuda", dtype=torch.float64) * 0.25
+    W[:T, 2] = W[:T, 0] + 2 * W[:T, 1]
+    W[:T, 3] = 1.0
+    J = eng.Jslots[0]
+    call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, ptr(W), 4, ds.Tp, D, 4, ptr(J), ldj, ldj * ldj, 0, None)
+    torch.cuda.synchronize()
+    L = [torch.tril(J[k, :D, :D]) for k in range(4)]
+    scale = L[2].abs().max().item()
+    assert (L[2] - (L[0] + 2 * L[1])).abs().max().item() <= 1e-12 * scale                      # linearity in omega
+    X = ds.X[:T, :D]
+    for k in range(4):
+        tr = torch.diagonal(L[k]).sum().item()
+        want = (W[:T, k, None] * X * X).sum().item()
+        assert abs(tr - want) <= 1e-11 * abs(want)                                               # trace identity
+    cols = slice(2000, 2256)
+    ref = X.t() @ X[:, cols]                                                                     # (D, 256) fp64 reference
+    got = J[3, :D, cols]
+    mask = torch.arange(D, device="cuda")[:, None] >= torch.arange(2000, 2256, device="cuda")[None, :]
+    assert ((got - ref)[mask]).abs().max().item() <= 1e-11 * ref.abs().max().item()
+    blk = J[3, 1280:1408, 1280:1408]                                                             # a diagonal tile is written in full
+    assert (blk - blk.t()).abs().max().item() <= 1e-12 * blk.abs().max().item()
+    # border sums  [Omega|Kappa]' [X, 1]
+    OK = torch.zeros(ds.Tp, 2 * eng.ldn, dtype=torch.float64, device="cuda")
+    OK[:T, :4] = W[:T]
+    OK[:T, eng.ldn:eng.ldn + 4] = Y_dev = torch.from_numpy(Y[:, :4]).cuda() - 0.5
+    call("pgl_contract_tn", ptr(OK), 2 * eng.ldn, 2 * eng.ldn, ptr(ds.X), Dp, Dp, ptr(eng.border), Dp, 2 * eng.ldn, D + 1, ds.Tp, 1.0, 0.0, None)
+    torch.cuda.synchronize()
+    want = OK[:T].t() @ ds.X[:T, :D + 1]
+    assert (eng.border[:, :D + 1] - want).abs().max().item() <= 1e-11 * want.abs().max().item()
+
+
+def test_cfg2_full_sweeps_invariants():
+    """configs[1] at full size: two complete resample_model() sweeps; checks that need no CPU replay:
+    the weight draw with z = 0 is the posterior mean (J_SS mu = h_S), with z = e_k it moves by L^-T e_k (U'U = J_SS);
+    the flips respect rho in {0,1}; log-likelihood equals the closed form from a torch fp64 activation; determinism."""
+    import torch
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.engine import make_draws, prior_terms
+    N, B, T = 128, 5, 50000
+    basis, Y, rng = _problem(N, B, T)
+    np.random.seed(0)
+    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=3)
+    model.add_data(Y)
+    eng = model.engine
+    for _ in range(2):
+        model.resample_model()
+    A, Wt, b = model.adjacency, model.weights, model.biases
+    assert np.all(Wt[~A] == 0) and np.all(np.isfinite(Wt)) and np.all(np.isfinite(b))
+    # closed-form log-likelihood from an independent fp64 activation
+    X = eng.datasets[0].X[:T, :eng.D]
+    psi = X @ torch.from_numpy((A[:, :, None] * Wt).reshape(N, -1).T).cuda() + torch.from_numpy(b).cuda()
+    Yd = torch.from_numpy(Y).cuda()
+    want = (Yd * psi - torch.log1p(torch.exp(psi))).sum().item()
+    assert abs(model.log_likelihood() - want) <= 1e-10 * abs(want)
+    # posterior-mean identity on the engine's last assembled batch: replay one sweep with z = 0 and rho in {0,1}
+    regs = model.regressions
+    a0, W0, b0 = model._local_state()
+    rho = np.where(a0, 1.0, 0.0)                       # deterministic sparsity: a stays as it is, no flips
+    S_w, mu_w = np.array([r.S_w for r in regs]), np.array([r.mu_w for r in regs])
+    hyp = prior_terms(S_w, mu_w, np.array([r.S_b[0, 0] for r in regs]), np.array([r.mu_b[0] for r in regs]))
+    perm, u, z = make_draws(1, 0, range(N), N, N * B)
+    a1, W1, b1, _ = eng.sweep(a0, W0, b0, rho, *hyp, perm, u, np.zeros_like(z), seed=3, sweep=7)
+    np.testing.assert_array_equal(a1, a0)
+    a2, W2, b2, _ = eng.sweep(a0, W0, b0, rho, *hyp, perm, u, np.zeros_like(z), seed=3, sweep=7)
+    np.testing.assert_array_equal(W1, W2)              # same seed/sweep -> bitwise reproducible
+    for n in (0, 17, N - 1):                           # J_SS mu = h_S on the assembled posterior
+        Jp, hp = eng.posterior(n)
+        m = np.concatenate((np.repeat(a0[n], B), [True]))
+        mu = np.concatenate((W1[n][a0[n]].ravel(), [b1[n]]))
+        resid = Jp[np.ix_(m, m)] @ mu - hp[m]
+        assert np.abs(resid).max() <= 1e-8 * np.abs(hp[m]).max()
+
+
+def test_dense_maximum_size_cholesky_path():
+    """a dense-prior regression (rho = 1, no flips, BASELINE.json configs[4] style) at D = 16384: the blocked Cholesky, the
+    triangular solves and the rank-64 MFMA updates on a 16385-dimensional system; checked through J mu = h."""
+    import torch
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    N, B, T = 2048, 8, 4000
+    basis, Y, rng = _problem(N, B, T, L=50, seed=2)
+    eng = GibbsEngine(N, B, 0, 2, batch=2)
+    eng.add_data(Y, basis=basis)
+    a = np.ones((2, N), dtype=bool)
+    W = np.zeros((2, N, B))
+    b = np.full(2, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * 0.5, (2, N, 1, 1)), np.zeros((2, N, B)), np.ones(2), np.full(2, -2.0))
+    perm, u, z = make_draws(5, 0, range(2), N, N * B)
+    a1, W1, b1, _ = eng.sweep(a, W, b, np.ones((2, N)), *hyp, perm, u, np.zeros_like(z), seed=5, sweep=0)
+    assert a1.all()
+    D = N * B
+    M = torch.tril(eng.Jbuf[1, :D + 2, :D + 2])
+    Jfull = M[:D + 1, :D + 1] + torch.tril(M[:D + 1, :D + 1], -1).t()
+    h = M[D + 1, :D + 1]
+    mu = torch.from_numpy(np.concatenate((W1[1].ravel(), [b1[1]]))).cuda()
+    resid = (Jfull @ mu - h).abs().max().item()
+    assert resid <= 1e-7 * h.abs().max().item()
+    # and the draw itself: x - mu = L^-T z  <=>  (x - mu)' J (x - mu) = z'z
+    a2, W2, b2, _ = eng.sweep(a, W, b, np.ones((2, N)), *hyp, perm, u, z, seed=5, sweep=0)
+    d = torch.from_numpy(np.concatenate((W2[1].ravel(), [b2[1]]))).cuda() - mu
+    q = (d @ (Jfull @ d)).item()
+    assert abs(q - float(z[1] @ z[1])) <= 1e-7 * float(z[1] @ z[1])
