@@ -19,6 +19,12 @@
 #include "pgl_common.h"
 #include <cstdlib>
 
+// ablation switches (tools/probe_gram.py) exist only in builds with -DPGL_ABLATION=1; production kernels carry no such branches
+#ifndef PGL_ABLATION
+#define PGL_ABLATION 0
+#endif
+#define DBG(bit) (PGL_ABLATION && (g.debug & (bit)))
+
 namespace {
 
 constexpr int BK = 16;
@@ -53,7 +59,7 @@ __device__ __forceinline__ void block_sync_lds() {
 }
 
 // one work item = one output tile of one batch (weighted mode: of one group of WZ weight columns)
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA = false>
 __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, double* smem) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     const int ntm = (g.M + C::BM - 1) / C::BM;
@@ -134,7 +140,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         for (int i = 0; i < 4; ++i) a[i] = As[kr * C::SA + i * 16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = Bs[kr * C::SB + j * 16];
-        if (WEIGHTED && !(g.debug & 2)) {
+        if (WEIGHTED && !DBG(2)) {
             const double wv = Ws[kr * WZ + wz];
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] *= wv;
@@ -151,12 +157,12 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         lstore(0);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
-            const int buf = (g.debug & 1) ? 0 : (kt & 1);
-            if (kt + 1 < nkt && !(g.debug & 1)) gload(kt + 1);
+            const int buf = DBG(1) ? 0 : (kt & 1);
+            if (kt + 1 < nkt && !DBG(1)) gload(kt + 1);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
-            if (kt + 1 < nkt && !(g.debug & 1)) lstore(buf ^ 1);
-            if (!(g.debug & 4)) __syncthreads();
+            if (kt + 1 < nkt && !DBG(1)) lstore(buf ^ 1);
+            if (!DBG(4)) __syncthreads();
         }
     } else {
         // three LDS stages, the barrier sits in the MIDDLE of a K tile: tile kt+1 is written to LDS (from registers loaded a
@@ -166,17 +172,52 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         // the raw fragments of k-step s+1 are fetched from LDS before the 16 MFMAs of step s are issued and are scaled by
         // omega after the first 8 of them, so neither the ds_read latency nor the v_mul_f64 -> MFMA dependency is exposed
         // (f64 VALU shares the MFMA pipe: only the multiplies' own ~4.5 cycles each remain).
-        gload(0);
-        lstore(0);
-        if (nkt > 1) gload(1);
-        __syncthreads();
+        // DMA staging (global_load_lds): one wave-instruction moves one 1-KiB tile row straight into LDS (lane-linear
+        // destination = exactly our row layout; the padded row stride only moves the per-instruction base).  Out-of-range
+        // columns are clamped to a readable one: they only feed outputs that are never stored.
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+        auto dma = [&](int kt, int stage) {
+            static_assert(!DMA || (C::BM == 128 && C::BN == 128 && C::THREADS == 512), "DMA staging is written for the Gram tile");
+            const long krow = (long)kt * BK;
+            double* As = smem + stage * C::STAGE;
+            double* Bs = As + C::A_ELEMS;
+            int ca = m0 + lane * 2, cb = n0 + lane * 2;
+            ca = ca < g.a_cols ? ca : g.a_cols - 2;
+            cb = cb < g.b_cols ? cb : g.b_cols - 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ab + (krow + r) * g.lda + ca), (lds_ptr_t)(As + r * C::SA), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bb + (krow + r) * g.ldb + cb), (lds_ptr_t)(Bs + r * C::SB), 16, 0, 0);
+            }
+            if (WEIGHTED && __builtin_amdgcn_readfirstlane(wave) == 0) {
+                // 16 x WZ doubles = 64 dwords: lane l carries dword l  -> double l/2 = (row (l/2)/WZ, column (l/2)%WZ)
+                const int dbl = lane >> 1, r = dbl / WZ, z = dbl % WZ;
+                int zc = batch * WZ + z;
+                zc = zc < g.nz_total ? zc : g.nz_total - 1;
+                const float* src = reinterpret_cast<const float*>(g.W + (krow + r) * g.ldw + zc) + (lane & 1);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + C::B_ELEMS), 4, 0, 0);
+            }
+        };
+        if constexpr (DMA) {
+            dma(0, 0);
+            if (nkt > 1) dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            gload(0);
+            lstore(0);
+            if (nkt > 1) gload(1);
+            __syncthreads();
+        }
         double fa[2][4] = {{1, 2, 3, 4}, {5, 6, 7, 8}}, fb[2][4] = {{1, 2, 3, 4}, {5, 6, 7, 8}}, fw[2] = {1, 1};
         auto fetch = [&](int buf, int kk, int set) {
             const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
             const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
             const double* Ws = smem + buf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
             const int kr = kk * 4 + frow;
-            if (g.debug & 8) return;                    // ablation: no fragment traffic at all (MFMA-only loop)
+            if DBG(8) return;                    // ablation: no fragment traffic at all (MFMA-only loop)
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[set][i] = As[kr * C::SA + i * 16];
 #pragma unroll
@@ -184,7 +225,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             fw[set] = WEIGHTED ? Ws[kr * WZ + wz] : 1.0;
         };
         auto scale = [&](int set) {
-            if (WEIGHTED && !(g.debug & 2)) {
+            if (WEIGHTED && !DBG(2)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa[set][i] *= fw[set];
             }
@@ -199,7 +240,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         fetch(0, 0, 0);
         scale(0);
         for (int kt = 0; kt < nkt; ++kt) {
-            const int nxt = (g.debug & 1) ? 0 : ((cur == 2) ? 0 : cur + 1);
+            const int nxt = DBG(1) ? 0 : ((cur == 2) ? 0 : cur + 1);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 const int set = kk & 1;
@@ -212,14 +253,22 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 __builtin_amdgcn_sched_barrier(0);
                 mma_half(set, 1);
                 if (kk == BK / 8 - 1) {
-                    if (kt + 1 < nkt && !(g.debug & 1)) {
-                        lstore(nxt);
-                        if (kt + 2 < nkt) gload(kt + 2);
+                    if constexpr (DMA) {
+                        // tile kt+1 was issued one tile ago (or in the prologue): wait for this wave's pieces, meet the other
+                        // waves, then reuse the stage last read in tile kt-1 for tile kt+2
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        block_sync_lds();
+                        if (kt + 2 < nkt) dma(kt + 2, (nxt == 2) ? 0 : nxt + 1);
+                    } else {
+                        if (kt + 1 < nkt && !DBG(1)) {
+                            lstore(nxt);
+                            if (kt + 2 < nkt) gload(kt + 2);
+                        }
+                        if (!DBG(4)) block_sync_lds();
                     }
-                    if (!(g.debug & 4)) block_sync_lds();
                 }
             }
-            if (!(g.debug & 1)) cur = nxt;
+            if (!DBG(1)) cur = nxt;
         }
     }
 
@@ -267,7 +316,7 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     const long total = (long)(g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn) * g.nbatch;
     const long chunk = (total + 7) / 8;
     long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (g.debug & 16) w = blockIdx.x;
+    if DBG(16) w = blockIdx.x;
     if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
     gemm_item<WM, WN, WZ, WEIGHTED, STAGES>(g, w, smem);
 }
@@ -276,7 +325,7 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
 // co-residency above is lost -- measured 1.5x panel reuse instead of ~30x at cfg3).  One workgroup per CU; each reads the
 // XCC it runs on and pulls consecutive items of that XCD's chunk from a counter, stealing from the next XCD when its own
 // chunk is exhausted.  Placement is used for speed only: any placement gives the same result.
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA>
 __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64_persistent(PglGemmArgs g) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -308,10 +357,10 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64_persistent(Pgl
         // microseconds (once per 25 ms work item) turns 31 of them into L2 hits.
         {
             const int rank = (int)(w & 31);
-            const int unit = g.debug >> 8;                  // s_sleep units (64 cycles) per rank
+            const int unit = g.debug >> 8;                  // PGL_GRAM_STAGGER experiment (0 in production)                  // s_sleep units (64 cycles) per rank
             for (int r = 0; r < rank * unit; r += 64) __builtin_amdgcn_s_sleep(64);
         }
-        gemm_item<WM, WN, WZ, WEIGHTED, STAGES>(g, w, smem);
+        gemm_item<WM, WN, WZ, WEIGHTED, STAGES, DMA>(g, w, smem);
     }
 }
 
@@ -351,12 +400,12 @@ static int* sched_slot(hipStream_t st) {
     return slot;
 }
 
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA>
 int launch_persistent(const PglGemmArgs& a0, hipStream_t st) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     static bool attr_set = false;
     static int n_cu = 0;
-    auto kern = gemm_tn_f64_persistent<WM, WN, WZ, WEIGHTED, STAGES>;
+    auto kern = gemm_tn_f64_persistent<WM, WN, WZ, WEIGHTED, STAGES, DMA>;
     constexpr size_t lds = C::LDS_BYTES + 16;     // + the work ticket
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -395,7 +444,9 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             b.debug = dbg;
             static const int persist = getenv("PGL_GRAM_PERSIST") ? atoi(getenv("PGL_GRAM_PERSIST")) : 1;
             if (variant == 2) return launch<2, 2, 2, true, 2>(b, st);
-            return persist ? launch_persistent<2, 2, 2, true, 3>(b, st) : launch<2, 2, 2, true, 3>(b, st);
+            static const int use_dma = getenv("PGL_GRAM_DMA") ? atoi(getenv("PGL_GRAM_DMA")) : 1;
+            if (!persist) return launch<2, 2, 2, true, 3>(b, st);
+            return use_dma ? launch_persistent<2, 2, 2, true, 3, true>(b, st) : launch_persistent<2, 2, 2, true, 3, false>(b, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
         case PGL_GEMM_TRI1: PGL_CHECK_ARG(a.M == a.N); return launch<2, 2, 1, false>(a, st);

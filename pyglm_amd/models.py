@@ -204,12 +204,18 @@ class NonlinearAutoregressiveModel(object):
         from .engine import make_draws, prior_terms
         regs = self.regressions[self.n0:self.n1]
         a, W, b = self._local_state()
-        rho = np.array([r.rho for r in regs])
-        S_w = np.array([r.S_w for r in regs])
-        mu_w = np.array([r.mu_w for r in regs])
-        S_b = np.array([r.S_b[0, 0] for r in regs])
-        mu_b = np.array([r.mu_b[0] for r in regs])
-        Jw, hw, Jb, hb, c0 = prior_terms(S_w, mu_w, S_b, mu_b)
+        versions = tuple(r._hyp_version for r in regs)
+        cache = getattr(self, "_hyper_cache", None)
+        if cache is not None and cache[0] == versions:
+            rho, Jw, hw, Jb, hb, c0 = cache[1]          # pushed by resample_network and untouched since
+        else:
+            rho = np.array([r.rho for r in regs])
+            S_w = np.array([r.S_w for r in regs])
+            mu_w = np.array([r.mu_w for r in regs])
+            S_b = np.array([r.S_b[0, 0] for r in regs])
+            mu_b = np.array([r.mu_b[0] for r in regs])
+            Jw, hw, Jb, hb, c0 = prior_terms(S_w, mu_w, S_b, mu_b)
+            self._hyper_cache = (versions, (rho, Jw, hw, Jb, hb, c0))
         perm, u, z = make_draws(self.seed, self.sweeps_done, range(self.n0, self.n1), self.N, self.N * self.B)
         a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done)
         self.sweeps_done += 1
@@ -265,6 +271,47 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
             reg.S_w = sigma[n]
             reg.mu_w = mu[n]
             reg.rho = rho[n]
+        self._cache_pushed_hypers(sigma, mu, rho)
+
+    def _cache_pushed_hypers(self, sigma, mu, rho):
+        """natural-parameter terms of the shard's rows for the hyper-parameters just pushed.  Network priors produce a
+        handful of distinct (mu, Sigma) blocks (off-diagonal / self-connection), so the B x B inversions are done once per
+        distinct block and scattered, instead of once per (n, m) pair."""
+        from .engine import prior_terms
+        n0, n1, N, B = self.n0, self.n1, self.N, self.B
+        regs = self.regressions[n0:n1]
+        sig = sigma[n0:n1].reshape(-1, B * B)
+        mus = mu[n0:n1].reshape(-1, B)
+        key = np.concatenate((sig, mus), axis=1)
+        # label every row with the index of its distinct block: two frequent candidates first, np.unique for the rest
+        label = np.full(key.shape[0], -1, dtype=np.int64)
+        blocks = []
+        for _ in range(2):
+            todo = np.nonzero(label < 0)[0]
+            if todo.size == 0:
+                break
+            cand = key[todo[0]]
+            label[todo[np.all(key[todo] == cand, axis=1)]] = len(blocks)
+            blocks.append(cand)
+        todo = np.nonzero(label < 0)[0]
+        if todo.size > 4 * (n1 - n0) + 8:                 # not a structured prior: let resample_regressions do the dense path
+            self._hyper_cache = None
+            return
+        if todo.size:
+            u_rest, inv = np.unique(key[todo], axis=0, return_inverse=True)
+            label[todo] = len(blocks) + inv.reshape(-1)
+            blocks.extend(list(u_rest))
+        u = np.array(blocks)
+        idx = label
+        Jw_u, hw_u, _, _, c0_u = prior_terms(u[:, :B * B].reshape(1, -1, B, B), u[:, B * B:].reshape(1, -1, B), np.ones(1), np.zeros(1))
+        nl = n1 - n0
+        Jw = Jw_u[0][idx].reshape(nl, N, B, B)
+        hw = hw_u[0][idx].reshape(nl, N, B)
+        c0 = c0_u[0][idx].reshape(nl, N)
+        S_b = np.array([r.S_b[0, 0] for r in regs])
+        mu_b = np.array([r.mu_b[0] for r in regs])
+        Jb = 1.0 / S_b
+        self._hyper_cache = (tuple(r._hyp_version for r in regs), (np.array(rho[n0:n1], dtype=float), Jw, hw, Jb, Jb * mu_b, c0))
 
 
 GLM = NonlinearAutoregressiveModel

@@ -30,11 +30,18 @@ class _SparseScalarRegressionBase(object):
         self.b = npr.multivariate_normal(self.mu_b, self.S_b)
         self._engine_cache = None
 
-    # hyper-parameter setters broadcast scalars (:95-136)
-    rho = property(lambda self: self._rho, lambda self, v: setattr(self, "_rho", expand_scalar(v, (self.N,))))
-    mu_w = property(lambda self: self._mu_w, lambda self, v: setattr(self, "_mu_w", expand_scalar(v, (self.N, self.B))))
-    mu_b = property(lambda self: self._mu_b, lambda self, v: setattr(self, "_mu_b", expand_scalar(v, (1,))))
-    S_w = property(lambda self: self._S_w, lambda self, v: setattr(self, "_S_w", expand_cov(v, (self.N, self.B, self.B))))
+    # hyper-parameter setters broadcast scalars (:95-136); every assignment bumps a version so that the population model
+    # can tell whether the natural-parameter terms it cached are still current
+    _hyp_version = 0
+
+    def _set(self, name, value):
+        setattr(self, name, value)
+        self._hyp_version = self._hyp_version + 1
+
+    rho = property(lambda self: self._rho, lambda self, v: self._set("_rho", expand_scalar(v, (self.N,))))
+    mu_w = property(lambda self: self._mu_w, lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B))))
+    mu_b = property(lambda self: self._mu_b, lambda self, v: self._set("_mu_b", expand_scalar(v, (1,))))
+    S_w = property(lambda self: self._S_w, lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B))))
 
     @property
     def S_b(self):
@@ -43,7 +50,7 @@ class _SparseScalarRegressionBase(object):
     @S_b.setter
     def S_b(self, value):
         assert np.isscalar(value)
-        self._S_b = expand_cov(value, (1, 1))
+        self._set("_S_b", expand_cov(value, (1, 1)))
 
     @property
     def natural_params(self):

@@ -118,3 +118,25 @@ def test_network_prior_shapes_and_niw_update():
         ours.resample(data)
         draws.append(ours.mu)
     np.testing.assert_allclose(np.mean(draws, 0), mu_n, atol=0.02)
+
+
+def test_pushed_hyper_cache_equals_dense_terms():
+    """the broadcast fast path taken after resample_network equals prior_terms on the full arrays, and is dropped as soon
+    as a hyper-parameter is set by hand"""
+    from pyglm_amd.engine import prior_terms
+    from pyglm_amd.models import SparseBernoulliGLM
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(2)
+    N, B = 7, 3
+    m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
+    m.resample_network()
+    versions, (rho, Jw, hw, Jb, hb, c0) = m._hyper_cache
+    regs = m.regressions
+    want = prior_terms(np.array([r.S_w for r in regs]), np.array([r.mu_w for r in regs]), np.array([r.S_b[0, 0] for r in regs]),
+                       np.array([r.mu_b[0] for r in regs]))
+    for got, w in zip((Jw, hw, Jb, hb, c0), want):
+        np.testing.assert_allclose(got, w, rtol=1e-13, atol=1e-15)
+    np.testing.assert_array_equal(rho, np.array([r.rho for r in regs]))
+    assert versions == tuple(r._hyp_version for r in regs)
+    regs[2].S_w = 5.0
+    assert versions != tuple(r._hyp_version for r in regs)      # stale cache is detected
