@@ -191,19 +191,24 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ab + (krow + r) * g.lda + ca), (lds_ptr_t)(As + r * C::SA), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bb + (krow + r) * g.ldb + cb), (lds_ptr_t)(Bs + r * C::SB), 16, 0, 0);
             }
-            if (WEIGHTED && __builtin_amdgcn_readfirstlane(wave) == 0) {
-                // 16 x WZ doubles = 64 dwords: lane l carries dword l  -> double l/2 = (row (l/2)/WZ, column (l/2)%WZ)
-                const int dbl = lane >> 1, r = dbl / WZ, z = dbl % WZ;
-                int zc = batch * WZ + z;
-                zc = zc < g.nz_total ? zc : g.nz_total - 1;
-                const float* src = reinterpret_cast<const float*>(g.W + (krow + r) * g.ldw + zc) + (lane & 1);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + C::B_ELEMS), 4, 0, 0);
+            if (WEIGHTED) {
+                // 16 x WZ doubles = 64 dwords, 8 per wave (lanes 0-7), so that every wave issues exactly 5 DMA instructions per
+                // tile and a counted s_waitcnt vmcnt(5) means "everything but my newest tile has landed" in every wave
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+                if (lane < 8) {
+                    const int dw = wv * 8 + lane, dbl = dw >> 1, r = dbl / WZ, z = dbl % WZ;
+                    int zc = batch * WZ + z;
+                    zc = zc < g.nz_total ? zc : g.nz_total - 1;
+                    const float* src = reinterpret_cast<const float*>(g.W + (krow + r) * g.ldw + zc) + (dw & 1);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(reinterpret_cast<float*>(Bs + C::B_ELEMS) + wv * 8), 4, 0, 0);
+                }
             }
         };
         if constexpr (DMA) {
             dma(0, 0);
-            if (nkt > 1) dma(1, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (nkt > 1) dma(1, 1);
+            if (STAGES >= 4 && nkt > 2) dma(2, 2);
             __syncthreads();
         } else {
             gload(0);
@@ -240,7 +245,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         fetch(0, 0, 0);
         scale(0);
         for (int kt = 0; kt < nkt; ++kt) {
-            const int nxt = DBG(1) ? 0 : ((cur == 2) ? 0 : cur + 1);
+            const int nxt = DBG(1) ? 0 : ((cur == STAGES - 1) ? 0 : cur + 1);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 const int set = kk & 1;
@@ -256,9 +261,18 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                     if constexpr (DMA) {
                         // tile kt+1 was issued one tile ago (or in the prologue): wait for this wave's pieces, meet the other
                         // waves, then reuse the stage last read in tile kt-1 for tile kt+2
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        block_sync_lds();
-                        if (kt + 2 < nkt) dma(kt + 2, (nxt == 2) ? 0 : nxt + 1);
+                        if constexpr (STAGES >= 4) {
+                            // tiles kt+1 and kt+2 are in flight (5 DMA instructions each per wave): tile kt+1 must have landed.
+                            // Near the end fewer tiles are outstanding and the counted wait is conservative (waits for less).
+                            if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            block_sync_lds();
+                            if (kt + 3 < nkt) dma(kt + 3, (cur == 0) ? STAGES - 1 : cur - 1);
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            block_sync_lds();
+                            if (kt + 2 < nkt) dma(kt + 2, (nxt == 2) ? 0 : nxt + 1);
+                        }
                     } else {
                         if (kt + 1 < nkt && !DBG(1)) {
                             lstore(nxt);
@@ -446,6 +460,7 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             if (variant == 2) return launch<2, 2, 2, true, 2>(b, st);
             static const int use_dma = getenv("PGL_GRAM_DMA") ? atoi(getenv("PGL_GRAM_DMA")) : 1;
             if (!persist) return launch<2, 2, 2, true, 3>(b, st);
+            if (use_dma && variant == 4) return launch_persistent<2, 2, 2, true, 4, true>(b, st);
             return use_dma ? launch_persistent<2, 2, 2, true, 3, true>(b, st) : launch_persistent<2, 2, 2, true, 3, false>(b, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
