@@ -156,7 +156,7 @@ def main():
             "config": {"workload": "SparseBernoulliGLM N=%d B=%d L=%d T=%d, i.i.d. Bernoulli(0.08) spikes, neurons sharded over %d GPU(s)"
                                    % (N, B, L, T, world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
                        "neurons_per_batch": model.engine.nb},
-            "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64<2,2,2,weighted> (omega-weighted Gram)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
                          "traffic": traffic, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
