@@ -236,10 +236,12 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             }
         };
         auto mma_half = [&](int set, int h) {
+            if (DBG(32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 2 * h; i < 2 * h + 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+            if (DBG(32)) __builtin_amdgcn_s_setprio(0);
         };
         int cur = 0;
         fetch(0, 0, 0);

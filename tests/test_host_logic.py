@@ -140,3 +140,27 @@ def test_pushed_hyper_cache_equals_dense_terms():
     assert versions == tuple(r._hyp_version for r in regs)
     regs[2].S_w = 5.0
     assert versions != tuple(r._hyp_version for r in regs)      # stale cache is detected
+
+
+def test_api_error_behaviour_matches_reference():
+    """bare asserts as in the reference: models.py:68-70, 77 (add_data), regression.py:135 (S_b must be a scalar),
+    networks.py:39-41 (resample input types)"""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.regression import SparseBernoulliRegression
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(0)
+    m = SparseBernoulliGLM(3, B=2, seed=1, engine_factory=OracleEngine)
+    with pytest.raises(AssertionError):
+        m.add_data(np.zeros((10, 4)))                 # wrong number of neurons
+    with pytest.raises(AssertionError):
+        m.add_data([[0, 1, 0]])                       # not an ndarray
+    with pytest.raises(AssertionError):
+        m.add_data(np.zeros((10, 3)), X=np.zeros((10, 3, 5)))
+    r = SparseBernoulliRegression(3, 2)
+    with pytest.raises(AssertionError):
+        r.S_b = np.eye(1)
+    with pytest.raises(Exception):
+        r._flatten_X(np.zeros(5))
+    assert m.generate(T=0).shape == (0, 3)
+    with pytest.raises(AssertionError):
+        m.generate(T=2.5)
