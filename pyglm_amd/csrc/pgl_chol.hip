@@ -176,21 +176,39 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     if (na_max <= 0) return PGL_OK;
     hipLaunchKernelGGL(gather_active_kernel, dim3((na_max + 255) / 256, na_max, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
-    for (int q0 = 0; q0 < na_max; q0 += NBC) {
+    // 128-row super-panels: two 64-row sub-panels (diagonal factor + row-panel solve each, with a rank-64 update of the
+    // second sub-panel's 64-row strip in between), then ONE rank-128 update of the trailing matrix -- half the passes over
+    // the trailing matrix of a plain 64-row right-looking factorisation.
+    auto trailing = [&](int krow0, int K, int c0, int mfix) -> int {
+        // C[c0.., c0..] -= P' P with P = rows [krow0, krow0+K) of Ac, columns from c0 (k-major panel)
+        PglGemmArgs t{};
+        const double* P = s.Ac + (long)krow0 * s.ldc + c0;
+        const int rem = na_max - c0;
+        t.A = P; t.lda = s.ldc; t.strideA = s.strideC;
+        t.B = P; t.ldb = s.ldc; t.strideB = s.strideC;
+        t.C = s.Ac + (long)c0 * s.ldc + c0; t.ldc = s.ldc; t.strideC = s.strideC;
+        t.N = rem; t.K = K; t.a_cols = rem + (rem & 1); t.b_cols = t.a_cols; t.nbatch = s.nb; t.nz_total = 0;
+        t.alpha = -1.0; t.beta = 1.0; t.batch_k = nullptr; t.batch_dim = s.na; t.dim_off = c0; t.W = nullptr; t.ldw = 0;
+        if (mfix > 0) { t.M = mfix; t.tri = 0; t.dim_mode = 1; return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st); }   // strip: mfix rows only
+        t.M = rem; t.tri = 2; t.dim_mode = 0;
+        return pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
+    };
+    for (int q0 = 0; q0 < na_max; q0 += 2 * NBC) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0);
         PGL_CHECK_LAUNCH();
-        const int rem = na_max - q0 - NBC;
+        int rem = na_max - q0 - NBC;
         if (rem <= 0) break;
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + 255) / 256, s.nb), dim3(256), 0, st, g, q0);
         PGL_CHECK_LAUNCH();
-        PglGemmArgs t{};
-        const double* P = s.Ac + (long)q0 * s.ldc + (q0 + NBC);   // U12: [64][rem], k-major
-        t.A = P; t.lda = s.ldc; t.strideA = s.strideC;
-        t.B = P; t.ldb = s.ldc; t.strideB = s.strideC;
-        t.C = s.Ac + (long)(q0 + NBC) * s.ldc + (q0 + NBC); t.ldc = s.ldc; t.strideC = s.strideC;
-        t.M = rem; t.N = rem; t.K = NBC; t.a_cols = rem + (rem & 1); t.b_cols = t.a_cols; t.nbatch = s.nb; t.nz_total = 0;
-        t.alpha = -1.0; t.beta = 1.0; t.tri = 2; t.batch_k = nullptr; t.batch_dim = s.na; t.dim_off = q0 + NBC; t.W = nullptr; t.ldw = 0;
-        int rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
+        int rc = trailing(q0, NBC, q0 + NBC, NBC);          // strip: rows/cols of the second sub-panel
+        if (rc) return rc;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0 + NBC);
+        PGL_CHECK_LAUNCH();
+        rem = na_max - q0 - 2 * NBC;
+        if (rem <= 0) break;
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + 255) / 256, s.nb), dim3(256), 0, st, g, q0 + NBC);
+        PGL_CHECK_LAUNCH();
+        rc = trailing(q0, 2 * NBC, q0 + 2 * NBC, 0);        // rank-128 update of everything right of / below the super-panel
         if (rc) return rc;
     }
     hipLaunchKernelGGL(solve_sample_kernel, dim3(s.nb), dim3(256), 0, st, g);

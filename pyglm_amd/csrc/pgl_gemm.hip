@@ -69,7 +69,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     if (g.tri) { tm = isqrt_tri(tile); tn = tile - tm * (tm + 1) / 2; if (g.tri == 2) { const int s_ = tm; tm = tn; tn = s_; } }
     else { tm = tile % ntm; tn = tile / ntm; }
     int Mv = g.M, Nv = g.N;
-    if (g.batch_dim) { Mv = g.batch_dim[batch] - g.dim_off; Nv = Mv; }
+    if (g.batch_dim) { Nv = g.batch_dim[batch] - g.dim_off; if (g.dim_mode == 0) Mv = Nv; }
     if (tm * C::BM >= Mv || tn * C::BN >= Nv) return;
 
     int K = g.K;
