@@ -86,12 +86,14 @@ typedef struct {
     int* d_idx; double* d_sign; int* d_cnt;   /* [nb][kmax], [nb][kmax], [nb]: pivot list of the pending tableau update */
     int* batch_k;                        /* [nb] scratch */
     double* G;                           /* [nb][kmax][kmax] scratch */
+    double* Lws;                         /* [nb][(kmax+1)^2] scratch: sub-tableau of the current proposal window */
     double* Ut; double* Wt; long ldu;    /* [nb][kmax][ldu] scratch, ldu >= D+2, even */
     int* status;                         /* [nb] sticky flags: 1 non-PD block, 2 singular pivot, 4 non-PD posterior */
 } pgl_flip_t;
 int pgl_flip_kmax(void);                         /* pivots (scalar rows) per tableau update */
 int pgl_flip_window_blocks(int B);               /* blocks proposed per window */
-int pgl_flip_apply(const pgl_flip_t* s, void* hip_stream);              /* sweep the tableau on the listed pivots */
+int pgl_flip_apply(const pgl_flip_t* s, void* hip_stream);              /* sweep the tableau on the listed pivots (<= 128 per call is fast) */
+int pgl_flip_apply_window(const pgl_flip_t* s, void* hip_stream);       /* same, right after pgl_flip_decide (which already left G = (M_DD)^-1) */
 int pgl_flip_decide(const pgl_flip_t* s, int window, void* hip_stream); /* run one window of proposals; fills the pivot list */
 
 /* ---- weight conditional (pyglm/regression.py:323-340) ---------------------------------------------------------- */

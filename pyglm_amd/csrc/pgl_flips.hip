@@ -23,8 +23,8 @@
 
 namespace {
 
-constexpr int KMAX = 128;   // max pivots (scalar rows) per tableau update
-constexpr int KWIN = 96;    // max scalar rows of blocks in one proposal window
+constexpr int KMAX = 320;   // max pivots (scalar rows) per tableau update = max scalar rows of the blocks of one proposal window
+constexpr int KWIN = KMAX;  // the window's sub-tableau and the pivot-block inverse live in an L2-resident global scratch, not in LDS
 
 struct FlipArgs {
     double* M; long ldj; long strideM;           // tableau per neuron
@@ -40,6 +40,7 @@ struct FlipArgs {
     int* d_cnt;                                  // [nb]
     int* batch_k;                                // [nb]  padded K for the MFMA update (0 = nothing to do)
     double* G;                                   // [nb][KMAX][KMAX]
+    double* Lws;                                 // [nb][(KMAX+1)^2] window sub-tableau scratch
     double* Ut; double* Wt; long ldu;            // [nb][KMAX][ldu]
     int* status;                                 // [nb] sticky error flags (1 = non-PD block met)
 };
@@ -53,15 +54,16 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
     const int N = g.N, B = g.B, D = N * B;
     const int k0 = window * g.R;
     const int nblk = min(g.R, N - k0);
-    if (nblk <= 0 || (g.skip && g.skip[n])) { if (tid == 0) g.d_cnt[n] = 0; return; }
-    const int nl = nblk * B + 1, ldl = nl + 1;
-    double* L = lds;                         // [nl][ldl]
-    double* Tm = L + (size_t)nl * ldl;       // [nl][B]
-    double* Cinv = Tm + (size_t)nl * B;      // [B][B]
+    if (nblk <= 0 || (g.skip && g.skip[n])) { if (tid == 0) { g.d_cnt[n] = 0; g.batch_k[n] = 0; } return; }
+    const int nl = nblk * B + 1, ldl = nl;
+    double* L = g.Lws + (size_t)n * (KMAX + 1) * (KMAX + 1);   // [nl][ldl], global (stays in this CU's L1 / the XCD's L2)
+    double* Tm = lds;                        // [nl][B]
+    double* Prow = Tm + (size_t)nl * B;      // [B][nl]  pivot rows of the block being swept
+    double* Cinv = Prow + (size_t)nl * B;    // [B][B]
     double* Cb = Cinv + B * B;               // [B][B] cholesky scratch
     double* vb = Cb + B * B;                 // [B]
     __shared__ int s_flip, s_sign;
-    __shared__ int s_flipped[KWIN];
+    __shared__ int s_flipped[KMAX];
 
     const double* M = g.M + (long)n * g.strideM;
     const int* perm = g.perm + (long)n * N;
@@ -143,12 +145,27 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
                 Tm[e] = s;
             }
             __syncthreads();
-            for (int e = tid; e < nl * nl; e += 256) {   // non-pivot entries
-                const int i = e / nl, j = e % nl;
-                if ((i >= p0 && i < p0 + B) || (j >= p0 && j < p0 + B)) continue;
-                double s = 0.0;
-                for (int x = 0; x < B; ++x) s += Tm[i * B + x] * L[(p0 + x) * ldl + j];
-                L[i * ldl + j] -= s;
+            for (int e = tid; e < nl * B; e += 256) {    // pivot rows -> LDS
+                const int x = e / nl, j = e % nl;
+                Prow[e] = L[(p0 + x) * ldl + j];
+            }
+            __syncthreads();
+            // non-pivot entries: the sub-tableau lives in global memory (L2), so the read-modify-writes are issued in batches of
+            // 8 independent loads per thread instead of one dependent load/store at a time
+            for (int e0 = tid; e0 < nl * nl; e0 += 256 * 8) {
+                double old_[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int e = e0 + q * 256; old_[q] = (e < nl * nl) ? L[(e / nl) * ldl + e % nl] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * 256;
+                    if (e >= nl * nl) continue;
+                    const int i = e / nl, j = e % nl;
+                    if ((i >= p0 && i < p0 + B) || (j >= p0 && j < p0 + B)) continue;
+                    double sum = 0.0;
+                    for (int x = 0; x < B; ++x) sum += Tm[i * B + x] * Prow[x * nl + j];
+                    L[i * ldl + j] = old_[q] - sum;
+                }
             }
             __syncthreads();
             const double sg = (flip_sign > 0) ? 1.0 : -1.0;
@@ -168,6 +185,34 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
                 for (int b = 0; b < B; ++b) { g.d_idx[(long)n * KMAX + cnt] = m * B + b; g.d_sign[(long)n * KMAX + cnt] = (double)s_flipped[k]; ++cnt; }
             }
         g.d_cnt[n] = cnt;
+        g.batch_k[n] = (cnt + 15) & ~15;
+    }
+    __syncthreads();
+    // G = (M_DD)^-1 of the PRE-window tableau comes for free: after the local sweeps the flipped rows hold
+    // M'_DD = -Sg G Sg, hence G[q][r] = -s_q s_r L[loc q][loc r]
+    {
+        __shared__ int s_loc[KMAX];
+        __shared__ int s_cnt;
+        if (tid == 0) {
+            int cnt = 0;
+            for (int k = 0; k < nblk; ++k)
+                if (s_flipped[k])
+                    for (int b = 0; b < B; ++b) s_loc[cnt++] = k * B + b;
+            s_cnt = cnt;
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        double* Gn = g.G + (long)n * KMAX * KMAX;
+        const int kp = (cnt + 15) & ~15;
+        for (int e = tid; e < kp * KMAX; e += 256) {
+            const int q = e / KMAX, r = e % KMAX;
+            double v = 0.0;
+            if (q < cnt && r < cnt) {
+                const double sq = (double)s_flipped[s_loc[q] / B], sr = (double)s_flipped[s_loc[r] / B];
+                v = -sq * sr * L[s_loc[q] * ldl + s_loc[r]];
+            }
+            Gn[e] = v;
+        }
     }
 }
 
@@ -178,9 +223,12 @@ __global__ __launch_bounds__(256) void invert_kernel(FlipArgs g) {
     const int k = g.d_cnt[n];
     double* Gn = g.G + (long)n * KMAX * KMAX;
     if (k <= 0) { if (tid == 0) g.batch_k[n] = 0; return; }
-    const int ld = k + 1;
-    double* A = lds;                 // [k][ld]
-    double* colp = A + (size_t)k * ld;   // [k]
+    // chunks of up to 128 pivots (what the initial sweep uses) are inverted in LDS; larger lists fall back to the slow
+    // in-place global path (proposal windows never come here: decide_kernel emits their G directly)
+    const bool in_lds = k <= 128;
+    const int ld = in_lds ? k + 1 : KMAX;
+    double* colp = lds;              // [KMAX]
+    double* A = in_lds ? lds + KMAX : Gn;
     const double* M = g.M + (long)n * g.strideM;
     const int* idx = g.d_idx + (long)n * KMAX;
     for (int e = tid; e < k * k; e += 256) {
@@ -208,9 +256,17 @@ __global__ __launch_bounds__(256) void invert_kernel(FlipArgs g) {
         __syncthreads();
     }
     // all-forward sweep of the whole block gives -A^-1
-    for (int e = tid; e < KMAX * KMAX; e += 256) {
-        const int i = e / KMAX, j = e % KMAX;
-        Gn[e] = (i < k && j < k) ? -A[i * ld + j] : 0.0;
+    if (in_lds) {
+        for (int e = tid; e < KMAX * KMAX; e += 256) {
+            const int i = e / KMAX, j = e % KMAX;
+            Gn[e] = (i < k && j < k) ? -A[i * ld + j] : 0.0;
+        }
+    } else {
+        __syncthreads();
+        for (int e = tid; e < KMAX * KMAX; e += 256) {
+            const int i = e / KMAX, j = e % KMAX;
+            Gn[e] = (i < k && j < k) ? -Gn[e] : 0.0;
+        }
     }
     if (tid == 0) { g.batch_k[n] = (k + 15) & ~15; if (s_bad) atomicOr(&g.status[n], 2); }
 }
@@ -270,7 +326,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
 
 size_t pgl_k_flip_lds_decide(int B, int R) {
     const int nl = R * B + 1;
-    return ((size_t)nl * (nl + 1) + (size_t)nl * B + 2 * (size_t)B * B + B) * sizeof(double);
+    return (2 * (size_t)nl * B + 2 * (size_t)B * B + B) * sizeof(double);
 }
 
 static int set_lds(const void* fn, size_t bytes) {
@@ -283,21 +339,23 @@ static int set_lds(const void* fn, size_t bytes) {
 struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
-    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Ut; double* Wt; long ldu; int* status;
+    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
 };
 
 int pgl_k_flip_window_blocks(int B) { int r = KWIN / B; return r < 1 ? 0 : r; }
 
 // apply the pivot list currently in (d_idx, d_sign, d_cnt) to every neuron's tableau
-int pgl_k_flip_apply(const PglFlipState& s, hipStream_t st) {
+int pgl_k_flip_apply(const PglFlipState& s, int have_G, hipStream_t st) {
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, pgl_k_flip_window_blocks(s.B), s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Ut, s.Wt, s.ldu, s.status};
-    const size_t lds_inv = ((size_t)KMAX * (KMAX + 1) + KMAX) * sizeof(double);
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status};
+    const size_t lds_inv = ((size_t)KMAX + 128 * 129) * sizeof(double);
     static bool once = false;
     if (!once) { int rc = set_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv); if (rc) return rc; once = true; }
     const int Md = s.N * s.B + 2;
-    hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);
-    PGL_CHECK_LAUNCH();
+    if (!have_G) {
+        hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);
+        PGL_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu + 255) / 256), s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
     // Wt = G Ut   (K x ldu), then  M -= Wt' Ut  on lower-triangular tiles
@@ -326,7 +384,7 @@ int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
     const int R = pgl_k_flip_window_blocks(s.B);
     if (R < 1) { pgl_set_error("B=%d exceeds the window capacity %d", s.B, KWIN); return PGL_ERR_ARG; }
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Ut, s.Wt, s.ldu, s.status};
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status};
     const size_t lds = pgl_k_flip_lds_decide(s.B, R);
     static size_t lds_set = 0;
     if (lds > lds_set) { int rc = set_lds(reinterpret_cast<const void*>(decide_kernel), lds); if (rc) return rc; lds_set = lds; }

@@ -77,7 +77,7 @@ class GibbsEngine(object):
             raise ValueError("B=%d too large for the proposal window" % self.B)
         self.datasets = []
         self.stream = torch.cuda.current_stream(self.dev)
-        per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + self.kmax * self.kmax * 8
+        per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
         if batch is None:
             free, _ = torch.cuda.mem_get_info(self.dev)
             budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * 0.45)
@@ -129,6 +129,7 @@ class GibbsEngine(object):
         self.Ac = self._z(nb, ldj, ldj)
         self.hc = self._z(2, nb, ldj)
         self.G = self._z(nb, kmax, kmax)
+        self.Lws = self._z(nb, (kmax + 1) * (kmax + 1))
         self.Ut = self._z(nb, kmax, ldj)
         self.Wt_ws = self._z(nb, kmax, ldj)
         self.d_idx = self._z(nb, kmax, dtype=I32)
@@ -337,7 +338,7 @@ class GibbsEngine(object):
             self.Mtab[:nbb].copy_(self.Jbuf[:nbb])
             fs = FlipState(ptr(self.Mtab), ldj, strideJ, nbb, N, B, off4(dev["perm"], s * N), off8(dev["u"], s * N), off8(dev["rho"], s * N),
                            off8(dev["c0"], s * N), off4(self.a_dev, s * N), off4(skip, s), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt),
-                           ptr(self.batch_k), ptr(self.G), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s))
+                           ptr(self.batch_k), ptr(self.G), ptr(self.Lws), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s))
             # initial sweep on S0 = {bias} U {active blocks}, in chunks of kmax pivots
             lists = []
             for i in range(nbb):
@@ -347,12 +348,13 @@ class GibbsEngine(object):
                     blocks = np.nonzero(a_host[s + i])[0]
                     rows = (blocks[:, None] * B + np.arange(B)[None, :]).ravel()
                     lists.append(np.concatenate(([D], rows)).astype(np.int32))
-            nchunk = max((len(l) + kmax - 1) // kmax for l in lists)
+            ck = 128                                     # pivots per initial chunk: inverted in LDS by pgl_flip_apply
+            nchunk = max((len(l) + ck - 1) // ck for l in lists)
             for c in range(nchunk):
                 idx = np.zeros((self.nb, kmax), dtype=np.int32)
                 cnt = np.zeros(self.nb, dtype=np.int32)
                 for i, l in enumerate(lists):
-                    part = l[c * kmax:(c + 1) * kmax]
+                    part = l[c * ck:(c + 1) * ck]
                     idx[i, :len(part)] = part
                     cnt[i] = len(part)
                 self.d_idx.copy_(torch.from_numpy(idx))
@@ -362,7 +364,7 @@ class GibbsEngine(object):
             nwin = (N + self.R - 1) // self.R
             for w in range(nwin):
                 call("pgl_flip_decide", ctypes.byref(fs), w, st)
-                call("pgl_flip_apply", ctypes.byref(fs), st)
+                call("pgl_flip_apply_window", ctypes.byref(fs), st)
         self._toc(hf)
         hc_ = self._tic("weights")
         # ---- weights (regression.py:323-340)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libpyglm_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == declared_symbols()      # the ctypes table mirrors the header 1:1
     assert _lib.load().pgl_abi_version() == 1
-    assert _lib.load().pgl_flip_kmax() == 128 and _lib.load().pgl_flip_window_blocks(5) == 19
+    assert _lib.load().pgl_flip_kmax() == 320 and _lib.load().pgl_flip_window_blocks(5) == 64
 
 
 def test_struct_layouts_match_header_field_order():
