@@ -48,9 +48,9 @@ struct FlipArgs {
 __device__ __forceinline__ double tab_get(const double* M, long ld, int i, int j) { return i >= j ? M[(long)i * ld + j] : M[(long)j * ld + i]; }
 
 // ------------------------------------------------------------------ proposals of one window, in LDS
-__global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
+__global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int N = g.N, B = g.B, D = N * B;
     const int k0 = window * g.R;
     const int nblk = min(g.R, N - k0);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
 
     const double* M = g.M + (long)n * g.strideM;
     const int* perm = g.perm + (long)n * N;
-    for (int e = tid; e < nl * nl; e += 256) {
+    for (int e = tid; e < nl * nl; e += nthr) {
         const int i = e / nl, j = e % nl;
         const int gi = (i < nl - 1) ? perm[k0 + i / B] * B + i % B : D + 1;
         const int gj = (j < nl - 1) ? perm[k0 + j / B] * B + j % B : D + 1;
@@ -138,27 +138,27 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
                 for (int i = 0; i < B; ++i) Cinv[i * B + x] = sg * col[i];
             }
             __syncthreads();
-            for (int e = tid; e < nl * B; e += 256) {    // Tm = L[:,p] Cinv
+            for (int e = tid; e < nl * B; e += nthr) {    // Tm = L[:,p] Cinv
                 const int i = e / B, x = e % B;
                 double s = 0.0;
                 for (int y = 0; y < B; ++y) s += L[i * ldl + p0 + y] * Cinv[y * B + x];
                 Tm[e] = s;
             }
             __syncthreads();
-            for (int e = tid; e < nl * B; e += 256) {    // pivot rows -> LDS
+            for (int e = tid; e < nl * B; e += nthr) {    // pivot rows -> LDS
                 const int x = e / nl, j = e % nl;
                 Prow[e] = L[(p0 + x) * ldl + j];
             }
             __syncthreads();
             // non-pivot entries: the sub-tableau lives in global memory (L2), so the read-modify-writes are issued in batches of
             // 8 independent loads per thread instead of one dependent load/store at a time
-            for (int e0 = tid; e0 < nl * nl; e0 += 256 * 8) {
+            for (int e0 = tid; e0 < nl * nl; e0 += nthr * 8) {
                 double old_[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int e = e0 + q * 256; old_[q] = (e < nl * nl) ? L[(e / nl) * ldl + e % nl] : 0.0; }
+                for (int q = 0; q < 8; ++q) { const int e = e0 + q * nthr; old_[q] = (e < nl * nl) ? L[(e / nl) * ldl + e % nl] : 0.0; }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int e = e0 + q * 256;
+                    const int e = e0 + q * nthr;
                     if (e >= nl * nl) continue;
                     const int i = e / nl, j = e % nl;
                     if ((i >= p0 && i < p0 + B) || (j >= p0 && j < p0 + B)) continue;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
             }
             __syncthreads();
             const double sg = (flip_sign > 0) ? 1.0 : -1.0;
-            for (int e = tid; e < nl * B; e += 256) {    // pivot rows / columns
+            for (int e = tid; e < nl * B; e += nthr) {    // pivot rows / columns
                 const int i = e / B, x = e % B;
                 if (i >= p0 && i < p0 + B) { L[i * ldl + p0 + x] = -Cinv[(i - p0) * B + x]; }
                 else { const double val = sg * Tm[e]; L[i * ldl + p0 + x] = val; L[(p0 + x) * ldl + i] = val; }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void decide_kernel(FlipArgs g, int window) {
         const int cnt = s_cnt;
         double* Gn = g.G + (long)n * KMAX * KMAX;
         const int kp = (cnt + 15) & ~15;
-        for (int e = tid; e < kp * KMAX; e += 256) {
+        for (int e = tid; e < kp * KMAX; e += nthr) {
             const int q = e / KMAX, r = e % KMAX;
             double v = 0.0;
             if (q < cnt && r < cnt) {
@@ -388,7 +388,7 @@ int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
     const size_t lds = pgl_k_flip_lds_decide(s.B, R);
     static size_t lds_set = 0;
     if (lds > lds_set) { int rc = set_lds(reinterpret_cast<const void*>(decide_kernel), lds); if (rc) return rc; lds_set = lds; }
-    hipLaunchKernelGGL(decide_kernel, dim3(s.nb), dim3(256), lds, st, g, window);
+    hipLaunchKernelGGL(decide_kernel, dim3(s.nb), dim3(1024), lds, st, g, window);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
