@@ -20,6 +20,7 @@ CONFIGS = {   # BASELINE.json configs
     "cfg1": dict(N=4, B=1, T=10000, L=100),
     "cfg2": dict(N=128, B=5, T=50000, L=100),
     "cfg3": dict(N=1024, B=5, T=100000, L=100),
+    "cfg4": dict(N=512, B=5, T=100000, L=100, obs="negbin"),      # NegativeBinomialGLM (dense prior): PG shape b = y + xi
 }
 PEAK_F64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 64 cyc (tools/ubench2_f64.hip, measured)
 
@@ -103,13 +104,17 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM
     N, B, T, L = cfg["N"], cfg["B"], cfg["T"], cfg["L"]
     np.random.seed(0)
     basis, Y = synth(N, B, T, L)
     t_setup = time.perf_counter()
-    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=0,
-                               engine_kwargs=dict(batch=args.batch) if args.batch else None)
+    ekw = dict(batch=args.batch) if args.batch else None
+    if cfg.get("obs") == "negbin":
+        Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)     # counts, mean 0.35
+        model = NegativeBinomialGLM(N, basis=basis, regression_kwargs=dict(S_w=1.0, mu_b=-2.0, xi=2.0), seed=0, engine_kwargs=ekw)
+    else:
+        model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=0, engine_kwargs=ekw)
     model.add_data(Y)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
@@ -153,8 +158,8 @@ def main():
             "metric": "Gibbs sweeps/sec (full resample_model)", "value": args.steps / dt, "unit": "sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SparseBernoulliGLM N=%d B=%d L=%d T=%d, i.i.d. Bernoulli(0.08) spikes, neurons sharded over %d GPU(s)"
-                                   % (N, B, L, T, world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
+            "config": {"workload": "%s N=%d B=%d L=%d T=%d, synthetic i.i.d. %s, neurons sharded over %d GPU(s)"
+                                   % (type(model).__name__, N, B, L, T, "NB(2, 0.85) counts" if cfg.get("obs") == "negbin" else "Bernoulli(0.08) spikes", world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
                        "neurons_per_batch": model.engine.nb},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
@@ -162,7 +167,7 @@ def main():
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and cfg.get("obs") != "negbin":
             out["cpu_baseline"] = cpu_baseline(model, cfg)
         else:
             out["cpu_baseline"] = None

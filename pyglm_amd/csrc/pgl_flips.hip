@@ -342,7 +342,11 @@ struct PglFlipState {
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
 };
 
-int pgl_k_flip_window_blocks(int B) { int r = KWIN / B; return r < 1 ? 0 : r; }
+int pgl_k_flip_window_blocks(int B) {
+    int r = KWIN / B;                                   // blocks per window: at most KMAX pivots ...
+    while (r > 1 && pgl_k_flip_lds_decide(B, r) > 150 * 1024) --r;   // ... and the LDS scratch of decide_kernel must fit
+    return r < 1 ? 0 : r;
+}
 
 // apply the pivot list currently in (d_idx, d_sign, d_cnt) to every neuron's tableau
 int pgl_k_flip_apply(const PglFlipState& s, int have_G, hipStream_t st) {

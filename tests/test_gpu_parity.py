@@ -237,3 +237,68 @@ def test_sharded_equals_unsharded(torch_dev):
     for k in range(4):
         joined = np.concatenate([res[(0, 5)][k], res[(5, N)][k]])
         np.testing.assert_array_equal(joined, full[k])
+
+
+@pytest.mark.parametrize("N,B,T,rho", [(1, 3, 40, 0.5), (2, 1, 5, 0.5), (20, 10, 333, 0.5), (7, 32, 200, 0.6), (3, 2, 17, 0.0)])
+def test_edge_shapes_vs_oracle(torch_dev, N, B, T, rho):
+    """edges: a single neuron, T below one 16-row K tile / not a multiple of 16, the reference's default B = 10, the
+    largest supported B (= 32: 10 blocks per proposal window), rho = 0 everywhere (deterministic: all connections off)"""
+    from pyglm_amd.engine import make_draws
+    rng = np.random.default_rng(100 + N + B)
+    X = np.abs(rng.standard_normal((T, N, B))) * 0.4
+    Y = (rng.random((T, N)) < 0.3).astype(float)
+    kw = dict(rho=rho, S_w=2.0, mu_w=0.0, mu_b=-0.5, S_b=1.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.5 * a[:, :, None]
+    b = rng.standard_normal(N) * 0.3
+    eng = _engine(N, B)
+    eng.add_data(Y, X=X)
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    hyp = _hyp(regs)
+    perm, u, z = make_draws(77, 1, range(N), N, N * B)
+    a1, W1, b1, ll = eng.sweep(a, W, b, *hyp, perm, u, z, seed=77, sweep=1)
+    om = eng.datasets[0].OK[:T, :N].cpu().numpy()
+    outs = _oracle_sweep(N, B, X, Y, a, W, b, kw, om, perm, u, z)
+    for n, (ao, Wo, bo, _) in enumerate(outs):
+        np.testing.assert_array_equal(a1[n], ao)
+        np.testing.assert_allclose(W1[n], Wo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(b1[n], bo[0], rtol=1e-7, atol=1e-9)
+    if rho == 0.0:
+        assert not a1.any() and np.all(W1 == 0)
+
+
+def test_three_datasets_accumulate(torch_dev):
+    """data_list may hold several datasets whose sufficient statistics add (regression.py:237-260); the PG element index
+    continues across datasets"""
+    from pyglm_amd.engine import make_draws
+    rng = np.random.default_rng(9)
+    N, B = 6, 2
+    Ts = [150, 33, 400]
+    Xs = [np.abs(rng.standard_normal((T, N, B))) * 0.4 for T in Ts]
+    Ys = [(rng.random((T, N)) < 0.3).astype(float) for T in Ts]
+    kw = dict(rho=0.5, S_w=2.0, mu_w=0.1, mu_b=-0.5, S_b=1.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.5 * a[:, :, None]
+    b = rng.standard_normal(N) * 0.3
+    eng = _engine(N, B)
+    for X, Y in zip(Xs, Ys):
+        eng.add_data(Y, X=X)
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    hyp = _hyp(regs)
+    perm, u, z = make_draws(5, 3, range(N), N, N * B)
+    a1, W1, b1, ll = eng.sweep(a, W, b, *hyp, perm, u, z, seed=5, sweep=3)
+    oms = [ds.OK[:ds.T, :N].cpu().numpy() for ds in eng.datasets]
+    off = 0
+    for X, Y, om in zip(Xs, Ys, oms):              # the draws: element index = running time bin over the datasets
+        r = regs[2]
+        r.a, r.W, r.b = a[2], W[2], b[2:3]
+        want = orc.pg_draw(None, r.activation(X), 5, orc.stream_id(2, 3), off)
+        assert (np.abs(om[:, 2] - want) <= 1e-12 * want).mean() >= 0.99
+        off += X.shape[0]
+    for n in range(N):
+        r = orc.Regression(N, B, **kw)
+        r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+        np.testing.assert_allclose(ll[n], sum(r.log_likelihood(X, Y[:, n]).sum() for X, Y in zip(Xs, Ys)), rtol=1e-10)
+        r.resample([(X, Y[:, n]) for X, Y in zip(Xs, Ys)], [om[:, n] for om in oms], perm[n], u[n], z[n])
+        np.testing.assert_array_equal(a1[n], r.a)
+        np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
