@@ -13,9 +13,12 @@
 //     ds_read_b64 conflict-free and the global->LDS copy fully coalesced (1 KiB per wave-instruction).
 //   * wave tile 64x64 (16 accumulators, 128 VGPRs); workgroup = WM x WN x WZ waves.  WZ = 2 puts two
 //     neurons (two weight columns) on the same staged X tiles: 32 flop per byte staged.
-//   * LDS double buffer, register-staged prefetch of tile k+1 behind the MFMAs of tile k, one barrier per tile.
-//   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the 32
-//     workgroups resident on one XCD share the same X panels through that XCD's L2.
+//   * two pipelines: STAGES = 2 (register-staged prefetch, one barrier per K tile; the plain contraction and the rank-k
+//     updates) and STAGES = 3 with global_load_lds DMA staging, the barrier in the middle of a K tile and software-
+//     pipelined fragments (the Gram; see gemm_item below and DESIGN.md section 3.1).
+//   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the workgroups resident
+//     on one XCD share the same X panels through that XCD's L2; the Gram is launched persistently (one workgroup per
+//     CU pulling XCD-local items) because the dispatcher's round-robin drifts over long launches.
 #include "pgl_common.h"
 #include <cstdlib>
 
@@ -192,8 +195,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bb + (krow + r) * g.ldb + cb), (lds_ptr_t)(Bs + r * C::SB), 16, 0, 0);
             }
             if (WEIGHTED) {
-                // 16 x WZ doubles = 64 dwords, 8 per wave (lanes 0-7), so that every wave issues exactly 5 DMA instructions per
-                // tile and a counted s_waitcnt vmcnt(5) means "everything but my newest tile has landed" in every wave
+                // 16 x WZ doubles = 64 dwords, 8 per wave (lanes 0-7): every wave issues the same 5 DMA instructions per tile
                 const int wv = __builtin_amdgcn_readfirstlane(wave);
                 if (lane < 8) {
                     const int dw = wv * 8 + lane, dbl = dw >> 1, r = dbl / WZ, z = dbl % WZ;
@@ -208,7 +210,6 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             dma(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (nkt > 1) dma(1, 1);
-            if (STAGES >= 4 && nkt > 2) dma(2, 2);
             __syncthreads();
         } else {
             gload(0);
@@ -236,12 +237,10 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             }
         };
         auto mma_half = [&](int set, int h) {
-            if (DBG(32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 2 * h; i < 2 * h + 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-            if (DBG(32)) __builtin_amdgcn_s_setprio(0);
         };
         int cur = 0;
         fetch(0, 0, 0);
@@ -263,18 +262,9 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                     if constexpr (DMA) {
                         // tile kt+1 was issued one tile ago (or in the prologue): wait for this wave's pieces, meet the other
                         // waves, then reuse the stage last read in tile kt-1 for tile kt+2
-                        if constexpr (STAGES >= 4) {
-                            // tiles kt+1 and kt+2 are in flight (5 DMA instructions each per wave): tile kt+1 must have landed.
-                            // Near the end fewer tiles are outstanding and the counted wait is conservative (waits for less).
-                            if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            block_sync_lds();
-                            if (kt + 3 < nkt) dma(kt + 3, (cur == 0) ? STAGES - 1 : cur - 1);
-                        } else {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            block_sync_lds();
-                            if (kt + 2 < nkt) dma(kt + 2, (nxt == 2) ? 0 : nxt + 1);
-                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        block_sync_lds();
+                        if (kt + 2 < nkt) dma(kt + 2, (nxt == STAGES - 1) ? 0 : nxt + 1);
                     } else {
                         if (kt + 1 < nkt && !DBG(1)) {
                             lstore(nxt);
@@ -332,7 +322,6 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     const long total = (long)(g.tri ? ntm * (ntm + 1) / 2 : ntm * ntn) * g.nbatch;
     const long chunk = (total + 7) / 8;
     long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if DBG(16) w = blockIdx.x;
     if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
     gemm_item<WM, WN, WZ, WEIGHTED, STAGES>(g, w, smem);
 }
@@ -368,14 +357,6 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64_persistent(Pgl
         __syncthreads();
         const long w = ticket[0];
         if (w < 0) break;
-        // Stagger co-resident workgroups: requests for a line that is still in flight are not merged by the L2, so 32
-        // workgroups in perfect lockstep each fetch every panel line from the fabric.  A per-rank delay of a few
-        // microseconds (once per 25 ms work item) turns 31 of them into L2 hits.
-        {
-            const int rank = (int)(w & 31);
-            const int unit = g.debug >> 8;                  // PGL_GRAM_STAGGER experiment (0 in production)                  // s_sleep units (64 cycles) per rank
-            for (int r = 0; r < rank * unit; r += 64) __builtin_amdgcn_s_sleep(64);
-        }
         gemm_item<WM, WN, WZ, WEIGHTED, STAGES, DMA>(g, w, smem);
     }
 }
@@ -454,15 +435,13 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
     switch (kind) {
         case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); {
             static const int variant = getenv("PGL_GRAM_STAGES") ? atoi(getenv("PGL_GRAM_STAGES")) : 3;
-            static const int dbg = (getenv("PGL_GRAM_ABLATE") ? atoi(getenv("PGL_GRAM_ABLATE")) : 0) |
-                                   ((getenv("PGL_GRAM_STAGGER") ? atoi(getenv("PGL_GRAM_STAGGER")) : 0) << 8);
+            static const int dbg = getenv("PGL_GRAM_ABLATE") ? atoi(getenv("PGL_GRAM_ABLATE")) : 0;
             PglGemmArgs b = a;
             b.debug = dbg;
             static const int persist = getenv("PGL_GRAM_PERSIST") ? atoi(getenv("PGL_GRAM_PERSIST")) : 1;
             if (variant == 2) return launch<2, 2, 2, true, 2>(b, st);
             static const int use_dma = getenv("PGL_GRAM_DMA") ? atoi(getenv("PGL_GRAM_DMA")) : 1;
             if (!persist) return launch<2, 2, 2, true, 3>(b, st);
-            if (use_dma && variant == 4) return launch_persistent<2, 2, 2, true, 4, true>(b, st);
             return use_dma ? launch_persistent<2, 2, 2, true, 3, true>(b, st) : launch_persistent<2, 2, 2, true, 3, false>(b, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
