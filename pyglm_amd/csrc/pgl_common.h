@@ -45,7 +45,7 @@ struct PglGemmArgs {
     int* sched;                                // persistent launch: 8 per-XCD work counters, zeroed before the launch
     int debug;                                 // ablation switches for tools/probe_gram.py (0 in production)
     const int* batch_dim; int dim_off;         // optional per-batch size d = max(0, batch_dim[b] - dim_off)
-    int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d
+    int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);

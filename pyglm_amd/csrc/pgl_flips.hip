@@ -368,7 +368,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, hipStream_t st) {
     w.B = s.Ut; w.ldb = s.ldu; w.strideB = (long)KMAX * s.ldu;
     w.C = s.Wt; w.ldc = s.ldu; w.strideC = (long)KMAX * s.ldu;
     w.M = KMAX; w.N = (int)s.ldu; w.K = KMAX; w.a_cols = KMAX; w.b_cols = (int)s.ldu; w.nbatch = s.nb; w.nz_total = 0;
-    w.alpha = 1.0; w.beta = 0.0; w.tri = 0; w.batch_k = s.batch_k; w.batch_dim = nullptr; w.dim_off = 0; w.W = nullptr; w.ldw = 0;
+    w.alpha = 1.0; w.beta = 0.0; w.tri = 0; w.batch_k = s.batch_k; w.batch_dim = s.batch_k; w.dim_off = 0; w.dim_mode = 2; w.W = nullptr; w.ldw = 0;   // only the first K rows of W are non-zero / used
     int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st);
     if (rc) return rc;
     PglGemmArgs t{};

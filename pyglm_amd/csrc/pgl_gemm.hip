@@ -72,7 +72,12 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     if (g.tri) { tm = isqrt_tri(tile); tn = tile - tm * (tm + 1) / 2; if (g.tri == 2) { const int s_ = tm; tm = tn; tn = s_; } }
     else { tm = tile % ntm; tn = tile / ntm; }
     int Mv = g.M, Nv = g.N;
-    if (g.batch_dim) { Nv = g.batch_dim[batch] - g.dim_off; if (g.dim_mode == 0) Mv = Nv; }
+    if (g.batch_dim) {
+        const int d = g.batch_dim[batch] - g.dim_off;
+        if (g.dim_mode == 0) { Mv = d; Nv = d; }
+        else if (g.dim_mode == 1) Nv = d;
+        else Mv = d;
+    }
     if (tm * C::BM >= Mv || tn * C::BN >= Nv) return;
 
     int K = g.K;
