@@ -167,3 +167,84 @@ def test_negative_binomial_sweep_vs_oracle():
         np.testing.assert_array_equal(a1[n], r.a)
         np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(b1[n], r.b[0], rtol=1e-7, atol=1e-9)
+
+
+def test_random_shapes_fuzz_vs_oracle():
+    """ten seeded random (N, B, T, rho, batch, #datasets) draws, each one full sweep replayed by the oracle"""
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    master = np.random.default_rng(2024)
+    for trial in range(10):
+        N = int(master.integers(1, 48))
+        B = int(master.integers(1, 9))
+        nds = int(master.integers(1, 3))
+        Ts = [int(master.integers(3, 700)) for _ in range(nds)]
+        rho = float(master.choice([0.2, 0.5, 0.8, 1.0]))
+        batch = int(master.integers(1, N + 1))
+        rng = np.random.default_rng(trial)
+        Xs = [np.abs(rng.standard_normal((T, N, B))) * 0.4 for T in Ts]
+        Ys = [(rng.random((T, N)) < 0.3).astype(float) for T in Ts]
+        A = rng.standard_normal((N, N, B, B))
+        S_w = np.einsum("nmij,nmkj->nmik", A, A) * 0.3 + np.eye(B)
+        mu_w = rng.standard_normal((N, N, B)) * 0.2
+        rho_a = np.full((N, N), rho)
+        if rho < 1.0:
+            rho_a[rng.random((N, N)) < 0.1] = 1.0          # a few forced entries: exercises the NaN quirk of the reference
+        a = rng.random((N, N)) < 0.5
+        W = rng.standard_normal((N, N, B)) * 0.5 * a[:, :, None]
+        b = rng.standard_normal(N) * 0.3
+        S_b, mu_b = rng.random(N) + 0.5, rng.standard_normal(N)
+        eng = GibbsEngine(N, B, batch=batch)
+        for X, Y in zip(Xs, Ys):
+            eng.add_data(Y, X=X)
+        hyp = prior_terms(S_w, mu_w, S_b, mu_b)
+        perm, u, z = make_draws(trial, 0, range(N), N, N * B)
+        a1, W1, b1, _ = eng.sweep(a, W, b, rho_a, *hyp, perm, u, z, seed=trial, sweep=0)
+        oms = [ds.OK[:ds.T, :N].cpu().numpy() for ds in eng.datasets]
+        for n in range(N):
+            r = orc.Regression(N, B, rho=rho_a[n], S_w=S_w[n], mu_w=mu_w[n], S_b=float(S_b[n]), mu_b=float(mu_b[n]))
+            r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+            r.resample([(X, Y[:, n]) for X, Y in zip(Xs, Ys)], [om[:, n] for om in oms], perm[n], u[n], z[n])
+            msg = "trial %d (N=%d B=%d T=%s rho=%s batch=%d) neuron %d" % (trial, N, B, Ts, rho, batch, n)
+            np.testing.assert_array_equal(a1[n], r.a, err_msg=msg)
+            np.testing.assert_allclose(W1[n], r.W, rtol=1e-6, atol=1e-8, err_msg=msg)
+            np.testing.assert_allclose(b1[n], r.b[0], rtol=1e-6, atol=1e-8, err_msg=msg)
+
+
+def test_long_chain_matches_oracle_chain_statistically():
+    """300 sweeps of the README-size model on the GPU and 300 sweeps of the same model driven by the oracle (CPU) from
+    independent random streams: posterior summaries agree within Monte-Carlo error -- the GPU sampler targets the same law."""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.utils.basis import cosine_basis
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(11)
+    T, N, B, L = 4000, 4, 1, 50
+    basis = cosine_basis(B=B, L=L) / L
+    true = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.), seed=1, engine_factory=OracleEngine)
+    for n in range(N):
+        true.regressions[n].a[:] = False
+        true.regressions[n].W[:] = 0
+        true.regressions[n].a[n] = True
+        true.regressions[n].W[n, :] = -2.0
+        true.regressions[n].b[:] = -1.0
+    _, Y = true.generate(T=T, keep=False)
+    summaries = []
+    for factory, seed in [(None, 21), (OracleEngine, 22)]:
+        np.random.seed(5)
+        m = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.), seed=seed, engine_factory=factory)
+        m.add_data(Y)
+        As, Ws, bs = [], [], []
+        for it in range(300):
+            m.resample_model()
+            if it >= 100:
+                As.append(m.adjacency.copy())
+                Ws.append(m.weights[:, :, 0].copy())
+                bs.append(m.biases.copy())
+        summaries.append((np.mean(As, 0), np.mean(Ws, 0), np.mean(bs, 0)))
+    (A1, W1, b1), (A2, W2, b2) = summaries
+    print("GPU chain   A diag", np.diag(A1).round(2), "W diag", np.diag(W1).round(2), "b", b1.round(2))
+    print("oracle chain A diag", np.diag(A2).round(2), "W diag", np.diag(W2).round(2), "b", b2.round(2))
+    assert np.all(np.diag(A1) > 0.6) and np.all(np.diag(A2) > 0.6)          # the self-inhibition is found by both
+    np.testing.assert_allclose(np.diag(A1), np.diag(A2), atol=0.2)
+    np.testing.assert_allclose(np.diag(W1), np.diag(W2), atol=0.4)
+    np.testing.assert_allclose(b1, b2, atol=0.25)
+    assert np.abs(A1 - A2).max() < 0.35
