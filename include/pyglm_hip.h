@@ -103,6 +103,7 @@ typedef struct {
     int* act; long ldact; int* na;             /* [nb][ldact] scratch (ldact >= D+1), [nb] active sizes (out) */
     double* Ac; long ldc; long strideC;        /* [nb][ldc][ldc] scratch */
     double* hc;                                /* [2][nb][ldc] scratch */
+    double* Tinv;                              /* [nb][64][64] scratch */
     const double* z; long ldz;                 /* [nb][ldz] standard normals; the first na[n] are consumed (randn at sample_gaussian) */
     double* W; double* b;                      /* out: [nb][N*B] (zeros where a = 0), [nb] */
     int nb, N, B;

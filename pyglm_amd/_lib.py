@@ -18,7 +18,7 @@ class FlipState(ctypes.Structure):   # pgl_flip_t
 
 class CholState(ctypes.Structure):   # pgl_chol_t
     _fields_ = [("J", c_p), ("ldj", c_l), ("strideJ", c_l), ("a", c_p), ("act", c_p), ("ldact", c_l), ("na", c_p),
-                ("Ac", c_p), ("ldc", c_l), ("strideC", c_l), ("hc", c_p), ("z", c_p), ("ldz", c_l),
+                ("Ac", c_p), ("ldc", c_l), ("strideC", c_l), ("hc", c_p), ("Tinv", c_p), ("z", c_p), ("ldz", c_l),
                 ("W", c_p), ("b", c_p), ("nb", c_i), ("N", c_i), ("B", c_i), ("status", c_p)]
 
 

@@ -33,7 +33,7 @@ int pgl_k_flip_kmax(void);
 int pgl_k_flip_window_blocks(int);
 struct PglCholState {
     const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
-    double* Ac; long ldc; long strideC; double* hc; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
+    double* Ac; long ldc; long strideC; double* hc; double* Tinv; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
 };
 int pgl_k_chol_index(const PglCholState&, hipStream_t);
 int pgl_k_chol_sample(const PglCholState&, int, hipStream_t);
@@ -145,7 +145,7 @@ int pgl_flip_decide(const pgl_flip_t* s, int window, void* st) {
 }
 
 static PglCholState to_cstate(const pgl_chol_t* s) {
-    return PglCholState{s->J, s->ldj, s->strideJ, s->a, s->act, s->ldact, s->na, s->Ac, s->ldc, s->strideC, s->hc, s->z, s->ldz,
+    return PglCholState{s->J, s->ldj, s->strideJ, s->a, s->act, s->ldact, s->na, s->Ac, s->ldc, s->strideC, s->hc, s->Tinv, s->z, s->ldz,
                         s->W, s->b, s->nb, s->N, s->B, s->status};
 }
 int pgl_active_index(const pgl_chol_t* s, void* st) {
@@ -153,7 +153,7 @@ int pgl_active_index(const pgl_chol_t* s, void* st) {
     return pgl_k_chol_index(to_cstate(s), ST(st));
 }
 int pgl_sample_weights(const pgl_chol_t* s, int na_max, void* st) {
-    PGL_CHECK_ARG(s && s->J && s->act && s->na && s->Ac && s->hc && s->z && s->W && s->b && s->status);
+    PGL_CHECK_ARG(s && s->J && s->act && s->na && s->Ac && s->hc && s->Tinv && s->z && s->W && s->b && s->status);
     PGL_CHECK_ARG(na_max >= 1 && na_max <= s->N * s->B + 1 && s->ldc >= na_max + 1 && s->ldc % 2 == 0 && s->ldz >= na_max);
     return pgl_k_chol_sample(to_cstate(s), na_max, ST(st));
 }

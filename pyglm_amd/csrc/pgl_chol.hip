@@ -3,8 +3,9 @@
 // Reference: pyglm/regression.py:323-340 (_resample_W): Jp = J_post[ix_(a,a)], hp = h_post[a],
 // [W_active; b] = sample_gaussian(J=Jp, h=hp)  ==  L = chol(Jp);  x = L^-T z + Jp^-1 hp   (pybasicbayes, published form).
 // Steps here: (1) compact the active sub-block (both triangles) into Ac; (2) blocked right-looking Cholesky in the
-// UPPER form Ac = U'U (U = L'), so every panel U[q0:q0+64, :] is k-major and feeds the fp64 MFMA rank-64 update of the
-// trailing matrix directly (pgl_gemm.hip, upper-triangular tiles); (3) U'w = h, U mu = w, U x = z;  out = mu + x.
+// UPPER form Ac = U'U (U = L'), so every panel U[q0:q0+64, :] is k-major and feeds the fp64 MFMA contraction directly:
+// the 64 x 64 diagonal factor and its inverse are formed in LDS, the row-panel solve U12 = U11^-T A12 and the rank-64 /
+// rank-128 updates of the trailing matrix run on pgl_gemm.hip; (3) U'w = h, U mu = w, U x = z;  out = mu + x.
 #include "pgl_common.h"
 
 namespace {
@@ -18,6 +19,7 @@ struct CholArgs {
     int* na;                                   // [nb]
     double* Ac; long ldc; long strideC;        // [nb][ldc][ldc] compact active block -> U in place (upper)
     double* hc;                                // [nb][ldc]  h_active -> w -> mu
+    double* Tinv;                              // [nb][64][64] k-major inverse of the current diagonal factor (U11^-1)
     const double* z; long ldz;                 // [nb][ldz]
     double* W;                                 // [nb][N*B] out
     double* b;                                 // [nb] out
@@ -78,32 +80,24 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(CholArgs g, int q0) {
     }
     for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (i <= j) Ag[(long)i * g.ldc + j] = A[j][i]; }
     if (tid == 0 && s_bad) atomicOr(&g.status[n], 4);
-}
-
-// row panel: U12 = U11^-T A12 ; one thread per trailing column
-__global__ __launch_bounds__(256) void trsm_panel_kernel(CholArgs g, int q0) {
-    const int n = blockIdx.y, tid = threadIdx.x;
-    const int na = g.na[n];
-    if (q0 + NBC >= na) return;
-    __shared__ double U[NBC][NBC + 1];
-    double* Ab = g.Ac + (long)n * g.strideC;
-    for (int e = tid; e < NBC * NBC; e += 256) { const int i = e / NBC, j = e % NBC; U[i][j] = (i <= j) ? Ab[(long)(q0 + i) * g.ldc + q0 + j] : 0.0; }
-    __syncthreads();
-    const int c = q0 + NBC + blockIdx.x * 256 + tid;
-    if (c >= na) return;
-    double x[NBC];
-#pragma unroll
-    for (int i = 0; i < NBC; ++i) x[i] = Ab[(long)(q0 + i) * g.ldc + c];
-#pragma unroll
-    for (int i = 0; i < NBC; ++i) {
-        double s = x[i];
-#pragma unroll
-        for (int j = 0; j < NBC; ++j)
-            if (j < i) s -= U[j][i] * x[j];
-        x[i] = s / U[i][i];
+    // inverse of the lower factor, one column per thread (forward substitution on e_j); the row-panel solve
+    // U12 = U11^-T A12 = L^-1 A12 then runs on the MFMA contraction with Tinv[k][m] = (L^-1)[m][k] as its k-major operand
+    __shared__ double Li[NBC][NBC + 1];
+    if (tid < NBC) {
+        const int j = tid;
+        for (int i = 0; i < NBC; ++i) {
+            double sacc = (i == j) ? 1.0 : 0.0;
+            if (i < nb && j < nb) {
+                for (int k = j; k < i; ++k) sacc -= A[i][k] * Li[k][j];
+                Li[i][j] = (i >= j) ? sacc / A[i][i] : 0.0;
+            } else {
+                Li[i][j] = 0.0;
+            }
+        }
     }
-#pragma unroll
-    for (int i = 0; i < NBC; ++i) Ab[(long)(q0 + i) * g.ldc + c] = x[i];
+    __syncthreads();
+    double* Tn = g.Tinv + (long)n * NBC * NBC;
+    for (int e = tid; e < NBC * NBC; e += 256) { const int k = e / NBC, m = e % NBC; Tn[e] = Li[m][k]; }
 }
 
 // one workgroup per neuron:  U'w = h (forward, axpy form), U mu = w and U x = z (backward, dot form); scatter mu + x
@@ -157,11 +151,11 @@ __global__ __launch_bounds__(256) void solve_sample_kernel(CholArgs g) {
 
 struct PglCholState {
     const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
-    double* Ac; long ldc; long strideC; double* hc; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
+    double* Ac; long ldc; long strideC; double* hc; double* Tinv; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
 };
 
 static CholArgs mk(const PglCholState& s) {
-    return CholArgs{s.J, s.ldj, s.strideJ, s.a, s.act, s.ldact, s.na, s.Ac, s.ldc, s.strideC, s.hc, s.z, s.ldz, s.W, s.b, s.N, s.B, s.status};
+    return CholArgs{s.J, s.ldj, s.strideJ, s.a, s.act, s.ldact, s.na, s.Ac, s.ldc, s.strideC, s.hc, s.Tinv, s.z, s.ldz, s.W, s.b, s.N, s.B, s.status};
 }
 
 int pgl_k_chol_index(const PglCholState& s, hipStream_t st) {
@@ -193,21 +187,32 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
         t.M = rem; t.tri = 2; t.dim_mode = 0;
         return pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     };
+    auto panel_solve = [&](int q0) -> int {
+        // rows [q0, q0+64), columns from q0+64:  A12 <- L^-1 A12  (in place: a tile reads its 64 x 256 block completely before storing it)
+        const int c0 = q0 + NBC, rem = na_max - c0;
+        PglGemmArgs t{};
+        t.A = s.Tinv; t.lda = NBC; t.strideA = (long)NBC * NBC; t.a_cols = NBC;
+        t.B = s.Ac + (long)q0 * s.ldc + c0; t.ldb = s.ldc; t.strideB = s.strideC; t.b_cols = rem + (rem & 1);
+        t.C = s.Ac + (long)q0 * s.ldc + c0; t.ldc = s.ldc; t.strideC = s.strideC;
+        t.M = NBC; t.N = rem; t.K = NBC; t.nbatch = s.nb; t.alpha = 1.0; t.beta = 0.0; t.tri = 0;
+        t.batch_dim = s.na; t.dim_off = c0; t.dim_mode = 1;
+        return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st);
+    };
     for (int q0 = 0; q0 < na_max; q0 += 2 * NBC) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0);
         PGL_CHECK_LAUNCH();
         int rem = na_max - q0 - NBC;
         if (rem <= 0) break;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + 255) / 256, s.nb), dim3(256), 0, st, g, q0);
-        PGL_CHECK_LAUNCH();
-        int rc = trailing(q0, NBC, q0 + NBC, NBC);          // strip: rows/cols of the second sub-panel
+        int rc = panel_solve(q0);
+        if (rc) return rc;
+        rc = trailing(q0, NBC, q0 + NBC, NBC);              // strip: rows/cols of the second sub-panel
         if (rc) return rc;
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0 + NBC);
         PGL_CHECK_LAUNCH();
         rem = na_max - q0 - 2 * NBC;
         if (rem <= 0) break;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + 255) / 256, s.nb), dim3(256), 0, st, g, q0 + NBC);
-        PGL_CHECK_LAUNCH();
+        rc = panel_solve(q0 + NBC);
+        if (rc) return rc;
         rc = trailing(q0, 2 * NBC, q0 + 2 * NBC, 0);        // rank-128 update of everything right of / below the super-panel
         if (rc) return rc;
     }

@@ -128,6 +128,7 @@ class GibbsEngine(object):
         self.Mtab = self._z(nb, ldj, ldj)
         self.Ac = self._z(nb, ldj, ldj)
         self.hc = self._z(2, nb, ldj)
+        self.Tinv = self._z(nb, 64, 64)
         self.G = self._z(nb, kmax, kmax)
         self.Lws = self._z(nb, (kmax + 1) * (kmax + 1))
         self.Ut = self._z(nb, kmax, ldj)
@@ -369,7 +370,7 @@ class GibbsEngine(object):
         hc_ = self._tic("weights")
         # ---- weights (regression.py:323-340)
         cs = CholState(ptr(self.Jbuf), ldj, strideJ, off4(self.a_dev, s * N), ptr(self.act), D + 1, ptr(self.na), ptr(self.Ac), ldj, strideJ,
-                       ptr(self.hc), off8(dev["z"], s * (D + 1)), D + 1, off8(self.W_dev, s * D), off8(self.b_dev, s), nbb, N, B,
+                       ptr(self.hc), ptr(self.Tinv), off8(dev["z"], s * (D + 1)), D + 1, off8(self.W_dev, s * D), off8(self.b_dev, s), nbb, N, B,
                        off4(self.status, s))
         call("pgl_active_index", ctypes.byref(cs), st)
         na_max = int(self.na[:nbb].max().item())
