@@ -302,3 +302,35 @@ def test_three_datasets_accumulate(torch_dev):
         r.resample([(X, Y[:, n]) for X, Y in zip(Xs, Ys)], [om[:, n] for om in oms], perm[n], u[n], z[n])
         np.testing.assert_array_equal(a1[n], r.a)
         np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
+
+
+def test_mixed_deterministic_and_sampled_rows_in_one_batch(torch_dev):
+    """regression.py:153-155 / 274-275 is decided per regression: rows whose rho is all 0/1 take a = round(rho) and consume no
+    uniforms, the others run the collapsed flips -- both kinds inside the same device batch"""
+    from pyglm_amd.engine import make_draws
+    rng = np.random.default_rng(31)
+    N, B, T = 14, 3, 500
+    X = np.abs(rng.standard_normal((T, N, B))) * 0.4
+    Y = (rng.random((T, N)) < 0.3).astype(float)
+    rho = np.full((N, N), 0.5)
+    rho[2] = 1.0                                   # dense row
+    rho[5] = (rng.random(N) < 0.5).astype(float)   # fixed 0/1 pattern
+    rho[9] = 0.0                                   # empty row: bias only
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.5 * a[:, :, None]
+    b = rng.standard_normal(N) * 0.3
+    kw = dict(S_w=2.0, mu_w=0.0, mu_b=-0.5, S_b=1.0)
+    regs = [orc.Regression(N, B, rho=rho[n], **kw) for n in range(N)]
+    hyp = _hyp(regs)
+    eng = _engine(N, B, batch=9)
+    eng.add_data(Y, X=X)
+    perm, u, z = make_draws(3, 0, range(N), N, N * B)
+    a1, W1, b1, _ = eng.sweep(a, W, b, *hyp, perm, u, z, seed=3, sweep=0)
+    om = eng.datasets[0].OK[:T, :N].cpu().numpy()
+    for n, r in enumerate(regs):
+        r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+        r.resample([(X, Y[:, n])], [om[:, n]], perm[n], u[n], z[n])
+        np.testing.assert_array_equal(a1[n], r.a, err_msg="row %d" % n)
+        np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(b1[n], r.b[0], rtol=1e-7, atol=1e-9)
+    assert a1[2].all() and not a1[9].any() and np.array_equal(a1[5], rho[5].astype(bool))
