@@ -27,6 +27,12 @@
 #define PGL_ABLATION 0
 #endif
 #define DBG(bit) (PGL_ABLATION && (g.debug & (bit)))
+#if PGL_ABLATION
+__device__ long long g_pgl_dbg[8 * 256 * 4];   // per (workgroup < 256, wave): total, vmcnt wait, barrier wait, tiles
+extern "C" int pgl_debug_read(long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pgl_dbg), sizeof(long long) * n);
+}
+#endif
 
 namespace {
 
@@ -185,23 +191,26 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         // columns are clamped to a readable one: they only feed outputs that are never stored.
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-        auto dma = [&](int kt, int stage) {
+        // one tile = five DMA wave-instructions per wave: pieces 0..3 = (A row, B row) x 2, piece 4 = this wave's 8 weight dwords
+        auto dma_piece = [&](int kt, int stage, int p) {
             static_assert(!DMA || (C::BM == 128 && C::BN == 128 && C::THREADS == 512), "DMA staging is written for the Gram tile");
             const long krow = (long)kt * BK;
             double* As = smem + stage * C::STAGE;
             double* Bs = As + C::A_ELEMS;
-            int ca = m0 + lane * 2, cb = n0 + lane * 2;
-            ca = ca < g.a_cols ? ca : g.a_cols - 2;
-            cb = cb < g.b_cols ? cb : g.b_cols - 2;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ab + (krow + r) * g.lda + ca), (lds_ptr_t)(As + r * C::SA), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bb + (krow + r) * g.ldb + cb), (lds_ptr_t)(Bs + r * C::SB), 16, 0, 0);
-            }
-            if (WEIGHTED) {
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            if (p < 4) {
+                const int r = wv + 8 * (p >> 1);
+                if ((p & 1) == 0) {
+                    int ca = m0 + lane * 2;
+                    ca = ca < g.a_cols ? ca : g.a_cols - 2;
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ab + (krow + r) * g.lda + ca), (lds_ptr_t)(As + r * C::SA), 16, 0, 0);
+                } else {
+                    int cb = n0 + lane * 2;
+                    cb = cb < g.b_cols ? cb : g.b_cols - 2;
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bb + (krow + r) * g.ldb + cb), (lds_ptr_t)(Bs + r * C::SB), 16, 0, 0);
+                }
+            } else if (WEIGHTED) {
                 // 16 x WZ doubles = 64 dwords, 8 per wave (lanes 0-7): every wave issues the same 5 DMA instructions per tile
-                const int wv = __builtin_amdgcn_readfirstlane(wave);
                 if (lane < 8) {
                     const int dw = wv * 8 + lane, dbl = dw >> 1, r = dbl / WZ, z = dbl % WZ;
                     int zc = batch * WZ + z;
@@ -210,6 +219,10 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                     __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(reinterpret_cast<float*>(Bs + C::B_ELEMS) + wv * 8), 4, 0, 0);
                 }
             }
+        };
+        auto dma = [&](int kt, int stage) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) dma_piece(kt, stage, p);
         };
         if constexpr (DMA) {
             dma(0, 0);
@@ -248,6 +261,10 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
         };
         int cur = 0;
+#if PGL_ABLATION
+        long long dbg_vm = 0, dbg_bar = 0;
+        const long long dbg_t0 = __builtin_readcyclecounter();
+#endif
         fetch(0, 0, 0);
         scale(0);
         for (int kt = 0; kt < nkt; ++kt) {
@@ -255,21 +272,61 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 const int set = kk & 1;
-                if (kk + 1 < BK / 4) fetch(cur, kk + 1, set ^ 1);
-                else fetch(nxt, 0, set ^ 1);            // published by this tile's mid barrier (stale only after the last tile)
-                __builtin_amdgcn_sched_barrier(0);      // keep the ds_reads ahead of the MFMAs (hipcc sinks them otherwise)
-                mma_half(set, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                scale(set ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_half(set, 1);
+                if constexpr (DMA) {
+                    // Slotted k-step: LDS reads and DMA pieces are issued one instruction at a time in the shadow of an MFMA (a wave
+                    // issues in order: a cluster of 5 LDS reads or 5 DMA pieces keeps it from issuing its next MFMA for tens of
+                    // cycles: measured +3.3 % and +0.9 %).  The 4 omega multiplies stay ONE cluster: f64 VALU shares the MFMA
+                    // pipe and every switch MFMA -> VALU -> MFMA costs, so four isolated multiplies are 2 % slower than one group.
+                    // After MFMA m of this k-step:
+                    //   m = 0..3 / 4..7 / 8   read the A / B fragments and the weight of the NEXT k-step from LDS
+                    //   m = 9..11            (k-steps after the mid barrier) DMA pieces of tile kt+2
+                    //   m = 12               scale the next A fragments by omega
+                    const int fbuf = (kk + 1 < BK / 4) ? cur : nxt, fkk = (kk + 1 < BK / 4) ? kk + 1 : 0, ns = set ^ 1;
+                    const double* As_ = smem + fbuf * C::STAGE + wm * 64 + fcol;
+                    const double* Bs_ = smem + fbuf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
+                    const double* Ws_ = smem + fbuf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
+                    const int kr_ = fkk * 4 + frow;
+                    const bool do_dma = (kk >= BK / 8) && (kt + 2 < nkt);
+                    const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int i = m >> 2, j = m & 3;
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                        if (m < 4) fa[ns][m] = As_[kr_ * C::SA + m * 16];
+                        else if (m < 8) fb[ns][m - 4] = Bs_[kr_ * C::SB + (m - 4) * 16];
+                        else if (m == 8) fw[ns] = WEIGHTED ? Ws_[kr_ * WZ + wz] : 1.0;
+                        else if (m < 12) {
+                            const int piece = (kk - BK / 8) * 3 + (m - 9);       // kk = 2: pieces 0,1,2   kk = 3: pieces 3,4
+                            if (do_dma && piece < 5) dma_piece(kt + 2, dstage, piece);
+                        } else if (m == 12) scale(ns);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    if (kk + 1 < BK / 4) fetch(cur, kk + 1, set ^ 1);
+                    else fetch(nxt, 0, set ^ 1);            // published by this tile's mid barrier (stale only after the last tile)
+                    __builtin_amdgcn_sched_barrier(0);      // keep the ds_reads ahead of the MFMAs (hipcc sinks them otherwise)
+                    mma_half(set, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    scale(set ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_half(set, 1);
+                }
                 if (kk == BK / 8 - 1) {
                     if constexpr (DMA) {
                         // tile kt+1 was issued one tile ago (or in the prologue): wait for this wave's pieces, meet the other
                         // waves, then reuse the stage last read in tile kt-1 for tile kt+2
+#if PGL_ABLATION
+                        const long long t0_ = __builtin_readcyclecounter();
+#endif
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        block_sync_lds();
-                        if (kt + 2 < nkt) dma(kt + 2, (nxt == STAGES - 1) ? 0 : nxt + 1);
+#if PGL_ABLATION
+                        const long long t1_ = __builtin_readcyclecounter();
+#endif
+                        block_sync_lds();       // tile kt+2's DMA pieces are issued in the slots of the next two k-steps
+#if PGL_ABLATION
+                        const long long t2_ = __builtin_readcyclecounter();
+                        dbg_vm += t1_ - t0_; dbg_bar += t2_ - t1_;
+#endif
                     } else {
                         if (kt + 1 < nkt && !DBG(1)) {
                             lstore(nxt);
@@ -281,6 +338,12 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             }
             if (!DBG(1)) cur = nxt;
         }
+#if PGL_ABLATION
+        if (DBG(64) && blockIdx.x < 256 && lane == 0) {
+            long long* o = g_pgl_dbg + ((long)blockIdx.x * 8 + wave) * 4;
+            o[0] = __builtin_readcyclecounter() - dbg_t0; o[1] = dbg_vm; o[2] = dbg_bar; o[3] = nkt;
+        }
+#endif
     }
 
     // ---- epilogue.  f64 C/D fragment: row = (lane>>4) + 4*reg, col = lane&15 (verified on hardware)
