@@ -27,6 +27,9 @@
 #define PGL_ABLATION 0
 #endif
 #define DBG(bit) (PGL_ABLATION && (g.debug & (bit)))
+#ifndef PGL_PAIRED
+#define PGL_PAIRED 1
+#endif
 #if PGL_ABLATION
 __device__ long long g_pgl_dbg[8 * 256 * 4];   // per (workgroup < 256, wave): total, vmcnt wait, barrier wait, tiles
 extern "C" int pgl_debug_read(long long* host_out, int n) {
@@ -265,6 +268,63 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         long long dbg_vm = 0, dbg_bar = 0;
         const long long dbg_t0 = __builtin_readcyclecounter();
 #endif
+#if PGL_PAIRED
+        if constexpr (DMA) {
+            // Paired k-steps: the K tile is two pairs (even, odd) of k-steps.  All fragments of the NEXT pair are fetched in the
+            // MFMA shadows of the current pair and both of its A fragments are scaled by omega in ONE cluster of 8 multiplies at
+            // the end of the odd step -- two MFMA -> f64-VALU -> MFMA pipe switches per K tile instead of four.
+            double pa[2][2][4], pb[2][2][4], pw[2][2];      // [pair set][step in pair][fragment]
+            auto rdA = [&](int buf, int kk, int i) { return smem[buf * C::STAGE + wm * 64 + fcol + (kk * 4 + frow) * C::SA + i * 16]; };
+            auto rdB = [&](int buf, int kk, int j) { return smem[buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol + (kk * 4 + frow) * C::SB + j * 16]; };
+            auto rdW = [&](int buf, int kk) { return WEIGHTED ? smem[buf * C::STAGE + C::A_ELEMS + C::B_ELEMS + (kk * 4 + frow) * WZ + wz] : 1.0; };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pa[0][0][i] = rdA(0, 0, i); pa[0][1][i] = rdA(0, 1, i); pb[0][0][i] = rdB(0, 0, i); }
+            pw[0][0] = rdW(0, 0); pw[0][1] = rdW(0, 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pa[0][0][i] *= pw[0][0]; pa[0][1][i] *= pw[0][1]; }
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int nxt = (cur == STAGES - 1) ? 0 : cur + 1;
+                const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
+                const bool do_dma = kt + 2 < nkt;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int ps = p, ns = p ^ 1;
+                    const int nbuf = (p == 0) ? cur : nxt, nk = (p == 0) ? 2 : 0;       // where the next pair lives
+                    // ---- even step of the pair
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int i = m >> 2, j = m & 3;
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][0][i], pb[ps][0][j], acc[i][j], 0, 0, 0);
+                        if (m < 4) pb[ps][1][m] = rdB(cur, 2 * p + 1, m);
+                        else if (m < 8) pa[ns][0][m - 4] = rdA(nbuf, nk, m - 4);
+                        else if (m == 8) pw[ns][0] = rdW(nbuf, nk);
+                        else if (m == 9) pw[ns][1] = rdW(nbuf, nk + 1);
+                        else if (m < 15) { if (p == 1 && do_dma) dma_piece(kt + 2, dstage, m - 10); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // ---- odd step
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int i = m >> 2, j = m & 3;
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][1][i], pb[ps][1][j], acc[i][j], 0, 0, 0);
+                        if (m < 4) pa[ns][1][m] = rdA(nbuf, nk + 1, m);
+                        else if (m < 8) pb[ns][0][m - 4] = rdB(nbuf, nk, m - 4);
+                        else if (m == 12 && WEIGHTED) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { pa[ns][0][q] *= pw[ns][0]; pa[ns][1][q] *= pw[ns][1]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (p == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of tile kt+1 (issued a tile ago) have landed
+                        block_sync_lds();                                    // ... and everybody else's: tile kt+1 is readable
+                    }
+                }
+                cur = nxt;
+            }
+        } else
+#endif
+        {
         fetch(0, 0, 0);
         scale(0);
         for (int kt = 0; kt < nkt; ++kt) {
@@ -337,6 +397,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 }
             }
             if (!DBG(1)) cur = nxt;
+        }
         }
 #if PGL_ABLATION
         if (DBG(64) && blockIdx.x < 256 && lane == 0) {
