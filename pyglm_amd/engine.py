@@ -87,7 +87,6 @@ class GibbsEngine(object):
         if not design_only:
             self._alloc_batch()
         self.timings = {}
-        self.overlap = False     # two-stream Gram/post overlap: functional, but CU time is the shared resource -> no gain yet
         self.profile = False
         self._ev = []
 
@@ -123,7 +122,7 @@ class GibbsEngine(object):
 
     def _alloc_batch(self):
         nb, ldj, N, D, kmax = self.nb, self.ldj, self.N, self.D, self.kmax
-        self.Jslots = self._z(1, nb, ldj, ldj)      # one slot; a second one is only needed for the (disabled) two-stream overlap
+        self.Jslots = self._z(1, nb, ldj, ldj)
         self.Jbuf = self.Jslots[0]
         self.Mtab = self._z(nb, ldj, ldj)
         self.Ac = self._z(nb, ldj, ldj)
@@ -259,46 +258,12 @@ class GibbsEngine(object):
             arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
             dev[k] = torch.from_numpy(arr).to(self.dev)
         skip = torch.from_numpy(det.astype(np.int32)).to(self.dev)
-        # Batches are software-pipelined over two HIP streams: the Gram of batch k+1 (fp64-MFMA-bound) runs on `sG` while
-        # the tableau flips and the weight draw of batch k (HBM-bound rank-k updates) run on the higher-priority `sF`.
-        batches = [(s, min(self.nb, nloc - s)) for s in range(0, nloc, self.nb)]
-        main = torch.cuda.current_stream(self.dev)
-        if self.overlap and len(batches) > 1 and self.Jslots.shape[0] > 1:
-            if not hasattr(self, "_sG"):
-                self._sG = torch.cuda.Stream(self.dev)
-                self._sF = torch.cuda.Stream(self.dev, priority=-1)
-            sG, sF = self._sG, self._sF
-            ready = torch.cuda.Event()
-            ready.record(main)
-            sG.wait_event(ready)
-            sF.wait_event(ready)
-            gram_done = [torch.cuda.Event() for _ in batches]
-            slot_free = [None, None]
-            for k, (s, nbb) in enumerate(batches):
-                slot = k & 1
-                with torch.cuda.stream(sG):
-                    if slot_free[slot] is not None:
-                        sG.wait_event(slot_free[slot])
-                    self._gram(s, nbb, slot)
-                    gram_done[k].record(sG)
-                if k >= 1:
-                    ps, pn = batches[k - 1]
-                    with torch.cuda.stream(sF):
-                        sF.wait_event(gram_done[k - 1])
-                        self._post(ps, pn, (k - 1) & 1, a, det, dev, skip)
-                        slot_free[(k - 1) & 1] = torch.cuda.Event()
-                        slot_free[(k - 1) & 1].record(sF)
-            ps, pn = batches[-1]
-            with torch.cuda.stream(sF):
-                sF.wait_event(gram_done[-1])
-                self._post(ps, pn, (len(batches) - 1) & 1, a, det, dev, skip)
-                fin = torch.cuda.Event()
-                fin.record(sF)
-            main.wait_event(fin)
-        else:
-            for (s, nbb) in batches:
-                self._gram(s, nbb, 0)
-                self._post(s, nbb, 0, a, det, dev, skip)
+        # One batch after the other on the current stream.  (Running batch k's flips / weight draw on a second stream behind batch
+        # k+1's Gram was tried: bit-identical but no faster -- both stages compete for CU time)
+        for s0 in range(0, nloc, self.nb):
+            nbb = min(self.nb, nloc - s0)
+            self._gram(s0, nbb, 0)
+            self._post(s0, nbb, 0, a, det, dev, skip)
         torch.cuda.synchronize(self.dev)
         status = self.status.cpu().numpy()
         if status.any():
