@@ -30,6 +30,9 @@
 #ifndef PGL_PAIRED
 #define PGL_PAIRED 1
 #endif
+#ifndef PGL_WIDE
+#define PGL_WIDE 1
+#endif
 #if PGL_ABLATION
 __device__ long long g_pgl_dbg[8 * 256 * 4];   // per (workgroup < 256, wave): total, vmcnt wait, barrier wait, tiles
 extern "C" int pgl_debug_read(long long* host_out, int n) {
@@ -268,7 +271,69 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         long long dbg_vm = 0, dbg_bar = 0;
         const long long dbg_t0 = __builtin_readcyclecounter();
 #endif
-#if PGL_PAIRED
+#if PGL_PAIRED && PGL_WIDE
+        if constexpr (DMA) {
+            // Wide wave tile for the Gram: each of a neuron's four waves owns 32 rows x all 128 columns of the workgroup tile
+            // (2 A fragments x 8 B fragments per k-step instead of 4 x 4).  The omega multiplies scale A fragments, so this
+            // halves them (4 per pair of k-steps per wave, and no two waves scale the same A data any more) at the price of
+            // two more LDS reads per k-step.  Accumulator tile f = i*8 + j lives in acc[f >> 2][f & 3].
+            // Paired k-steps as below: all fragments of the NEXT pair are fetched in the MFMA shadows of the current pair, one
+            // cluster of multiplies per pair.
+            const int wq = wmn;                              // 0..3: 32-row slab of this wave
+            double pa[2][2][2], pb[2][2][8], pw[2][2];       // [pair set][step in pair][fragment]
+            auto rdA = [&](int buf, int kk, int i) { return smem[buf * C::STAGE + wq * 32 + fcol + (kk * 4 + frow) * C::SA + i * 16]; };
+            auto rdB = [&](int buf, int kk, int j) { return smem[buf * C::STAGE + C::A_ELEMS + fcol + (kk * 4 + frow) * C::SB + j * 16]; };
+            auto rdW = [&](int buf, int kk) { return smem[buf * C::STAGE + C::A_ELEMS + C::B_ELEMS + (kk * 4 + frow) * WZ + wz]; };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { pa[0][0][i] = rdA(0, 0, i); pa[0][1][i] = rdA(0, 1, i); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[0][0][j] = rdB(0, 0, j);
+            pw[0][0] = rdW(0, 0); pw[0][1] = rdW(0, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { pa[0][0][i] *= pw[0][0]; pa[0][1][i] *= pw[0][1]; }
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int nxt = (cur == STAGES - 1) ? 0 : cur + 1;
+                const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
+                const bool do_dma = kt + 2 < nkt;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int ps = p, ns = p ^ 1;
+                    const int nbuf = (p == 0) ? cur : nxt, nk = (p == 0) ? 2 : 0;
+                    // ---- even step: B fragments of this pair's odd step, A fragments + weights of the next pair, 4 DMA pieces
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int i = m >> 3, j = m & 7;
+                        acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][0][i], pb[ps][0][j], acc[m >> 2][m & 3], 0, 0, 0);
+                        if (m < 8) pb[ps][1][m] = rdB(cur, 2 * p + 1, m);
+                        else if (m < 10) pa[ns][0][m - 8] = rdA(nbuf, nk, m - 8);
+                        else if (m == 10) pw[ns][0] = rdW(nbuf, nk);
+                        else if (m == 11) pw[ns][1] = rdW(nbuf, nk + 1);
+                        else { if (p == 1 && do_dma) dma_piece(kt + 2, dstage, m - 12); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // ---- odd step: remaining fragments of the next pair, last DMA piece, the 4 multiplies in one cluster
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int i = m >> 3, j = m & 7;
+                        acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][1][i], pb[ps][1][j], acc[m >> 2][m & 3], 0, 0, 0);
+                        if (m < 2) pa[ns][1][m] = rdA(nbuf, nk + 1, m);
+                        else if (m < 10) pb[ns][0][m - 2] = rdB(nbuf, nk, m - 2);
+                        else if (m == 10) { if (p == 1 && do_dma) dma_piece(kt + 2, dstage, 4); }
+                        else if (m == 13) {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) { pa[ns][0][q] *= pw[ns][0]; pa[ns][1][q] *= pw[ns][1]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (p == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        block_sync_lds();
+                    }
+                }
+                cur = nxt;
+            }
+        } else
+#elif PGL_PAIRED
         if constexpr (DMA) {
             // Paired k-steps: the K tile is two pairs (even, odd) of k-steps.  All fragments of the NEXT pair are fetched in the
             // MFMA shadows of the current pair and both of its A fragments are scaled by omega in ONE cluster of 8 multiplies at
@@ -411,28 +476,30 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     if (!zvalid) return;
     double* __restrict__ Cb = g.C + (WEIGHTED ? (long)zg : (long)batch) * g.strideC;
     const double alpha = g.alpha, beta = g.beta;
+    // accumulator tile (i, j) of acc[4][4] -> offsets inside the workgroup tile: 64 x 64 wave tiles, or (wide Gram layout)
+    // tile f = 4 i + j of a 32 x 128 wave tile
+    constexpr bool WIDE = PGL_PAIRED && PGL_WIDE && DMA && STAGES == 3;
+    auto roff = [&](int i, int j) { return WIDE ? wmn * 32 + ((4 * i + j) >> 3) * 16 : wm * 64 + i * 16; };
+    auto coff = [&](int i, int j) { return WIDE ? ((4 * i + j) & 7) * 16 : wn * 64 + j * 16; };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         double cv[4][4];
         if (beta != 0.0) {   // all 16 read-modify-write loads of this row block in flight before the first use
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + frow + 4 * r;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int col = n0 + wn * 64 + j * 16 + fcol;
+                    const int row = m0 + roff(i, j) + frow + 4 * r, col = n0 + coff(i, j) + fcol;
                     cv[r][j] = (row < Mv && col < Nv) ? Cb[(long)row * g.ldc + col] : 0.0;
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 64 + i * 16 + frow + 4 * r;
-            if (row >= Mv) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + fcol;
-                if (col >= Nv) continue;
+                const int row = m0 + roff(i, j) + frow + 4 * r, col = n0 + coff(i, j) + fcol;
+                if (row >= Mv || col >= Nv) continue;
                 double v = alpha * acc[i][j][r];
                 if (beta != 0.0) v += beta * cv[r][j];
                 Cb[(long)row * g.ldc + col] = v;
