@@ -43,7 +43,6 @@ struct PglGemmArgs {
     int tri;                                   // 0: all tiles; 1: tiles tm >= tn (lower); 2: tiles tm <= tn (upper)
     const int* batch_k;                        // optional per-batch K (multiple of 16; 0 = skip batch)
     int* sched;                                // persistent launch: 8 per-XCD work counters, zeroed before the launch
-    int debug;                                 // ablation switches for tools/probe_gram.py (0 in production)
     const int* batch_dim; int dim_off;         // optional per-batch size d = max(0, batch_dim[b] - dim_off)
     int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed
 };

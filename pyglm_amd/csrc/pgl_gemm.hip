@@ -5,40 +5,24 @@
 // formed: omega scales the A fragment in registers), the batched activation Psi = X W' (:195-201), the
 // border sums X'omega, X'kappa (:253-260) and the symmetric rank-k updates of the flip tableau / Cholesky.
 //
-// Mapping to CDNA4 (measured, tools/ubench2_f64.hip): v_mfma_f64_16x16x4_f64 issues once per 64 cycles per
-// SIMD (78.6 TFLOP/s chip peak at 2.4 GHz) from a single wave with a single accumulator; f64 VALU shares
-// that pipe, so the only f64 VALU in the loop is the 4 weight multiplies per 16 MFMAs.
-//   * both operands are k-major ("TN"): a wave reads an A or B fragment as lanes (l&15) -> 16 consecutive
-//     doubles of row k0+(l>>4); LDS row stride = tile width + 16 doubles (== 16 mod 32) makes every
-//     ds_read_b64 conflict-free and the global->LDS copy fully coalesced (1 KiB per wave-instruction).
-//   * wave tile 64x64 (16 accumulators, 128 VGPRs); workgroup = WM x WN x WZ waves.  WZ = 2 puts two
-//     neurons (two weight columns) on the same staged X tiles: 32 flop per byte staged.
-//   * two pipelines: STAGES = 2 (register-staged prefetch, one barrier per K tile; the plain contraction and the rank-k
-//     updates) and STAGES = 3 with global_load_lds DMA staging, the barrier in the middle of a K tile and software-
-//     pipelined fragments (the Gram; see gemm_item below and DESIGN.md section 3.1).
-//   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the workgroups resident
-//     on one XCD share the same X panels through that XCD's L2; the Gram is launched persistently (one workgroup per
-//     CU pulling XCD-local items) because the dispatcher's round-robin drifts over long launches.
+// Mapping to CDNA4 (measured, tools/ubench2_f64.hip): v_mfma_f64_16x16x4_f64 issues once per 64 cycles per SIMD
+// (78.6 TFLOP/s chip peak at 2.4 GHz) from a single wave with a single accumulator; f64 VALU shares that pipe and every
+// MFMA -> VALU -> MFMA switch costs, so f64 VALU work inside the loop is kept minimal and clustered.
+//   * both operands are k-major ("TN"): a wave reads an A or B fragment as lanes (l&15) -> 16 consecutive doubles of row
+//     k0+(l>>4); LDS row stride = tile width + 16 doubles (== 16 mod 32) makes every fragment read conflict-free and the
+//     global->LDS copy fully coalesced (1 KiB per wave-instruction).
+//   * 16 accumulator tiles (128 VGPRs) per wave, workgroup = WM x WN x WZ waves; WZ = 2 puts two neurons (two weight
+//     columns) on the same staged X tiles: 32 flop per byte staged.
+//   * two pipelines in gemm_item: STAGES = 2 (register-staged prefetch, one barrier per K tile, 64 x 64 wave tiles: the plain
+//     contraction and the rank-k updates) and STAGES = 3, the Gram pipeline (global_load_lds DMA staging, barrier in the
+//     middle of a K tile, 32 x 128 wave tiles, every LDS read and DMA piece issued in the shadow of an MFMA, one cluster of
+//     omega multiplies per pair of k-steps).  DESIGN.md section 3.1 has the measurements behind each of these choices.
+//   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the workgroups resident on
+//     one XCD share the same X panels through that XCD's L2; the Gram is launched persistently (one workgroup per CU
+//     pulling XCD-local items) because the dispatcher's round-robin drifts over long launches.
 #include "pgl_common.h"
 #include <cstdlib>
 
-// ablation switches (tools/probe_gram.py) exist only in builds with -DPGL_ABLATION=1; production kernels carry no such branches
-#ifndef PGL_ABLATION
-#define PGL_ABLATION 0
-#endif
-#define DBG(bit) (PGL_ABLATION && (g.debug & (bit)))
-#ifndef PGL_PAIRED
-#define PGL_PAIRED 1
-#endif
-#ifndef PGL_WIDE
-#define PGL_WIDE 1
-#endif
-#if PGL_ABLATION
-__device__ long long g_pgl_dbg[8 * 256 * 4];   // per (workgroup < 256, wave): total, vmcnt wait, barrier wait, tiles
-extern "C" int pgl_debug_read(long long* host_out, int n) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pgl_dbg), sizeof(long long) * n);
-}
-#endif
 
 namespace {
 
@@ -160,7 +144,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         for (int i = 0; i < 4; ++i) a[i] = As[kr * C::SA + i * 16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = Bs[kr * C::SB + j * 16];
-        if (WEIGHTED && !DBG(2)) {
+        if (WEIGHTED) {
             const double wv = Ws[kr * WZ + wz];
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] *= wv;
@@ -177,21 +161,19 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         lstore(0);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
-            const int buf = DBG(1) ? 0 : (kt & 1);
-            if (kt + 1 < nkt && !DBG(1)) gload(kt + 1);
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) gload(kt + 1);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
-            if (kt + 1 < nkt && !DBG(1)) lstore(buf ^ 1);
-            if (!DBG(4)) __syncthreads();
+            if (kt + 1 < nkt) lstore(buf ^ 1);
+            __syncthreads();
         }
     } else {
-        // three LDS stages, the barrier sits in the MIDDLE of a K tile: tile kt+1 is written to LDS (from registers loaded a
-        // whole tile earlier) after the first half of tile kt's MFMAs, every wave passes the barrier, the second half runs.
-        // Stage (kt+1)%3 was last read in tile kt-2, which every wave had finished before it could pass the barrier of
-        // tile kt-1.  Because tile kt+1 is readable from the middle of tile kt on, the fragment pipeline never drains:
-        // the raw fragments of k-step s+1 are fetched from LDS before the 16 MFMAs of step s are issued and are scaled by
-        // omega after the first 8 of them, so neither the ds_read latency nor the v_mul_f64 -> MFMA dependency is exposed
-        // (f64 VALU shares the MFMA pipe: only the multiplies' own ~4.5 cycles each remain).
+        // ---- the Gram pipeline: three LDS stages filled by DMA, the barrier in the MIDDLE of a K tile.  Tile kt+1 (issued a whole
+        // tile earlier) is published by the barrier after the first pair of k-steps of tile kt; the DMA of tile kt+2 then reuses the
+        // stage last read in tile kt-1, which every wave had finished before it could pass the barrier.  Because tile kt+1 is
+        // readable from the middle of tile kt on, the fragment pipeline never drains at a tile boundary.
+        static_assert(DMA && WEIGHTED && STAGES == 3, "the 3-stage pipeline is the DMA-staged weighted Gram");
         // DMA staging (global_load_lds): one wave-instruction moves one 1-KiB tile row straight into LDS (lane-linear
         // destination = exactly our row layout; the padded row stride only moves the per-instruction base).  Out-of-range
         // columns are clamped to a readable one: they only feed outputs that are never stored.
@@ -230,49 +212,12 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
             for (int p = 0; p < 5; ++p) dma_piece(kt, stage, p);
         };
-        if constexpr (DMA) {
-            dma(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (nkt > 1) dma(1, 1);
-            __syncthreads();
-        } else {
-            gload(0);
-            lstore(0);
-            if (nkt > 1) gload(1);
-            __syncthreads();
-        }
-        double fa[2][4] = {{1, 2, 3, 4}, {5, 6, 7, 8}}, fb[2][4] = {{1, 2, 3, 4}, {5, 6, 7, 8}}, fw[2] = {1, 1};
-        auto fetch = [&](int buf, int kk, int set) {
-            const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
-            const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
-            const double* Ws = smem + buf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
-            const int kr = kk * 4 + frow;
-            if DBG(8) return;                    // ablation: no fragment traffic at all (MFMA-only loop)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[set][i] = As[kr * C::SA + i * 16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[set][j] = Bs[kr * C::SB + j * 16];
-            fw[set] = WEIGHTED ? Ws[kr * WZ + wz] : 1.0;
-        };
-        auto scale = [&](int set) {
-            if (WEIGHTED && !DBG(2)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[set][i] *= fw[set];
-            }
-        };
-        auto mma_half = [&](int set, int h) {
-#pragma unroll
-            for (int i = 2 * h; i < 2 * h + 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-        };
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nkt > 1) dma(1, 1);
+        __syncthreads();
         int cur = 0;
-#if PGL_ABLATION
-        long long dbg_vm = 0, dbg_bar = 0;
-        const long long dbg_t0 = __builtin_readcyclecounter();
-#endif
-#if PGL_PAIRED && PGL_WIDE
-        if constexpr (DMA) {
+        {
             // Wide wave tile for the Gram: each of a neuron's four waves owns 32 rows x all 128 columns of the workgroup tile
             // (2 A fragments x 8 B fragments per k-step instead of 4 x 4).  The omega multiplies scale A fragments, so this
             // halves them (4 per pair of k-steps per wave, and no two waves scale the same A data any more) at the price of
@@ -332,144 +277,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 }
                 cur = nxt;
             }
-        } else
-#elif PGL_PAIRED
-        if constexpr (DMA) {
-            // Paired k-steps: the K tile is two pairs (even, odd) of k-steps.  All fragments of the NEXT pair are fetched in the
-            // MFMA shadows of the current pair and both of its A fragments are scaled by omega in ONE cluster of 8 multiplies at
-            // the end of the odd step -- two MFMA -> f64-VALU -> MFMA pipe switches per K tile instead of four.
-            double pa[2][2][4], pb[2][2][4], pw[2][2];      // [pair set][step in pair][fragment]
-            auto rdA = [&](int buf, int kk, int i) { return smem[buf * C::STAGE + wm * 64 + fcol + (kk * 4 + frow) * C::SA + i * 16]; };
-            auto rdB = [&](int buf, int kk, int j) { return smem[buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol + (kk * 4 + frow) * C::SB + j * 16]; };
-            auto rdW = [&](int buf, int kk) { return WEIGHTED ? smem[buf * C::STAGE + C::A_ELEMS + C::B_ELEMS + (kk * 4 + frow) * WZ + wz] : 1.0; };
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { pa[0][0][i] = rdA(0, 0, i); pa[0][1][i] = rdA(0, 1, i); pb[0][0][i] = rdB(0, 0, i); }
-            pw[0][0] = rdW(0, 0); pw[0][1] = rdW(0, 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { pa[0][0][i] *= pw[0][0]; pa[0][1][i] *= pw[0][1]; }
-            for (int kt = 0; kt < nkt; ++kt) {
-                const int nxt = (cur == STAGES - 1) ? 0 : cur + 1;
-                const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
-                const bool do_dma = kt + 2 < nkt;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int ps = p, ns = p ^ 1;
-                    const int nbuf = (p == 0) ? cur : nxt, nk = (p == 0) ? 2 : 0;       // where the next pair lives
-                    // ---- even step of the pair
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        const int i = m >> 2, j = m & 3;
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][0][i], pb[ps][0][j], acc[i][j], 0, 0, 0);
-                        if (m < 4) pb[ps][1][m] = rdB(cur, 2 * p + 1, m);
-                        else if (m < 8) pa[ns][0][m - 4] = rdA(nbuf, nk, m - 4);
-                        else if (m == 8) pw[ns][0] = rdW(nbuf, nk);
-                        else if (m == 9) pw[ns][1] = rdW(nbuf, nk + 1);
-                        else if (m < 15) { if (p == 1 && do_dma) dma_piece(kt + 2, dstage, m - 10); }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    // ---- odd step
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        const int i = m >> 2, j = m & 3;
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][1][i], pb[ps][1][j], acc[i][j], 0, 0, 0);
-                        if (m < 4) pa[ns][1][m] = rdA(nbuf, nk + 1, m);
-                        else if (m < 8) pb[ns][0][m - 4] = rdB(nbuf, nk, m - 4);
-                        else if (m == 12 && WEIGHTED) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { pa[ns][0][q] *= pw[ns][0]; pa[ns][1][q] *= pw[ns][1]; }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (p == 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of tile kt+1 (issued a tile ago) have landed
-                        block_sync_lds();                                    // ... and everybody else's: tile kt+1 is readable
-                    }
-                }
-                cur = nxt;
-            }
-        } else
-#endif
-        {
-        fetch(0, 0, 0);
-        scale(0);
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int nxt = DBG(1) ? 0 : ((cur == STAGES - 1) ? 0 : cur + 1);
-#pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                const int set = kk & 1;
-                if constexpr (DMA) {
-                    // Slotted k-step: LDS reads and DMA pieces are issued one instruction at a time in the shadow of an MFMA (a wave
-                    // issues in order: a cluster of 5 LDS reads or 5 DMA pieces keeps it from issuing its next MFMA for tens of
-                    // cycles: measured +3.3 % and +0.9 %).  The 4 omega multiplies stay ONE cluster: f64 VALU shares the MFMA
-                    // pipe and every switch MFMA -> VALU -> MFMA costs, so four isolated multiplies are 2 % slower than one group.
-                    // After MFMA m of this k-step:
-                    //   m = 0..3 / 4..7 / 8   read the A / B fragments and the weight of the NEXT k-step from LDS
-                    //   m = 9..11            (k-steps after the mid barrier) DMA pieces of tile kt+2
-                    //   m = 12               scale the next A fragments by omega
-                    const int fbuf = (kk + 1 < BK / 4) ? cur : nxt, fkk = (kk + 1 < BK / 4) ? kk + 1 : 0, ns = set ^ 1;
-                    const double* As_ = smem + fbuf * C::STAGE + wm * 64 + fcol;
-                    const double* Bs_ = smem + fbuf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
-                    const double* Ws_ = smem + fbuf * C::STAGE + C::A_ELEMS + C::B_ELEMS;
-                    const int kr_ = fkk * 4 + frow;
-                    const bool do_dma = (kk >= BK / 8) && (kt + 2 < nkt);
-                    const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        const int i = m >> 2, j = m & 3;
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-                        if (m < 4) fa[ns][m] = As_[kr_ * C::SA + m * 16];
-                        else if (m < 8) fb[ns][m - 4] = Bs_[kr_ * C::SB + (m - 4) * 16];
-                        else if (m == 8) fw[ns] = WEIGHTED ? Ws_[kr_ * WZ + wz] : 1.0;
-                        else if (m < 12) {
-                            const int piece = (kk - BK / 8) * 3 + (m - 9);       // kk = 2: pieces 0,1,2   kk = 3: pieces 3,4
-                            if (do_dma && piece < 5) dma_piece(kt + 2, dstage, piece);
-                        } else if (m == 12) scale(ns);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-                    if (kk + 1 < BK / 4) fetch(cur, kk + 1, set ^ 1);
-                    else fetch(nxt, 0, set ^ 1);            // published by this tile's mid barrier (stale only after the last tile)
-                    __builtin_amdgcn_sched_barrier(0);      // keep the ds_reads ahead of the MFMAs (hipcc sinks them otherwise)
-                    mma_half(set, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    scale(set ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_half(set, 1);
-                }
-                if (kk == BK / 8 - 1) {
-                    if constexpr (DMA) {
-                        // tile kt+1 was issued one tile ago (or in the prologue): wait for this wave's pieces, meet the other
-                        // waves, then reuse the stage last read in tile kt-1 for tile kt+2
-#if PGL_ABLATION
-                        const long long t0_ = __builtin_readcyclecounter();
-#endif
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if PGL_ABLATION
-                        const long long t1_ = __builtin_readcyclecounter();
-#endif
-                        block_sync_lds();       // tile kt+2's DMA pieces are issued in the slots of the next two k-steps
-#if PGL_ABLATION
-                        const long long t2_ = __builtin_readcyclecounter();
-                        dbg_vm += t1_ - t0_; dbg_bar += t2_ - t1_;
-#endif
-                    } else {
-                        if (kt + 1 < nkt && !DBG(1)) {
-                            lstore(nxt);
-                            if (kt + 2 < nkt) gload(kt + 2);
-                        }
-                        if (!DBG(4)) block_sync_lds();
-                    }
-                }
-            }
-            if (!DBG(1)) cur = nxt;
         }
-        }
-#if PGL_ABLATION
-        if (DBG(64) && blockIdx.x < 256 && lane == 0) {
-            long long* o = g_pgl_dbg + ((long)blockIdx.x * 8 + wave) * 4;
-            o[0] = __builtin_readcyclecounter() - dbg_t0; o[1] = dbg_vm; o[2] = dbg_bar; o[3] = nkt;
-        }
-#endif
     }
 
     // ---- epilogue.  f64 C/D fragment: row = (lane>>4) + 4*reg, col = lane&15 (verified on hardware)
@@ -478,7 +286,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     const double alpha = g.alpha, beta = g.beta;
     // accumulator tile (i, j) of acc[4][4] -> offsets inside the workgroup tile: 64 x 64 wave tiles, or (wide Gram layout)
     // tile f = 4 i + j of a 32 x 128 wave tile
-    constexpr bool WIDE = PGL_PAIRED && PGL_WIDE && DMA && STAGES == 3;
+    constexpr bool WIDE = STAGES == 3;
     auto roff = [&](int i, int j) { return WIDE ? wmn * 32 + ((4 * i + j) >> 3) * 16 : wm * 64 + i * 16; };
     auto coff = [&](int i, int j) { return WIDE ? ((4 * i + j) & 7) * 16 : wn * 64 + j * 16; };
 #pragma unroll
@@ -630,15 +438,10 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
     PGL_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0);
     switch (kind) {
         case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); {
+            // production: persistent, DMA-staged 3-stage pipeline; PGL_GRAM_STAGES=2 selects the generic 2-stage kernel (debugging aid)
             static const int variant = getenv("PGL_GRAM_STAGES") ? atoi(getenv("PGL_GRAM_STAGES")) : 3;
-            static const int dbg = getenv("PGL_GRAM_ABLATE") ? atoi(getenv("PGL_GRAM_ABLATE")) : 0;
-            PglGemmArgs b = a;
-            b.debug = dbg;
-            static const int persist = getenv("PGL_GRAM_PERSIST") ? atoi(getenv("PGL_GRAM_PERSIST")) : 1;
-            if (variant == 2) return launch<2, 2, 2, true, 2>(b, st);
-            static const int use_dma = getenv("PGL_GRAM_DMA") ? atoi(getenv("PGL_GRAM_DMA")) : 1;
-            if (!persist) return launch<2, 2, 2, true, 3>(b, st);
-            return use_dma ? launch_persistent<2, 2, 2, true, 3, true>(b, st) : launch_persistent<2, 2, 2, true, 3, false>(b, st);
+            if (variant == 2) return launch<2, 2, 2, true, 2>(a, st);
+            return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
         case PGL_GEMM_TRI1: PGL_CHECK_ARG(a.M == a.N); return launch<2, 2, 1, false>(a, st);
