@@ -21,7 +21,9 @@ CONFIGS = {   # BASELINE.json configs
     "cfg2": dict(N=128, B=5, T=50000, L=100),
     "cfg3": dict(N=1024, B=5, T=100000, L=100),
     "cfg4": dict(N=512, B=5, T=100000, L=100, obs="negbin"),      # NegativeBinomialGLM (dense prior): PG shape b = y + xi
+    "cfg3g": dict(N=1024, B=5, T=100000, L=100, obs="gaussian"),  # not in BASELINE.json: SparseGaussianGLM at the cfg3 shape
 }
+PEAK_HBM_GBS = 8000.0
 PEAK_F64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 64 cyc (tools/ubench2_f64.hip, measured)
 
 
@@ -104,7 +106,7 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM
+    from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM, SparseGaussianGLM
     N, B, T, L = cfg["N"], cfg["B"], cfg["T"], cfg["L"]
     np.random.seed(0)
     basis, Y = synth(N, B, T, L)
@@ -113,6 +115,10 @@ def main():
     if cfg.get("obs") == "negbin":
         Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)     # counts, mean 0.35
         model = NegativeBinomialGLM(N, basis=basis, regression_kwargs=dict(S_w=1.0, mu_b=-2.0, xi=2.0), seed=0, engine_kwargs=ekw)
+    elif cfg.get("obs") == "gaussian":
+        rg = np.random.default_rng(1)
+        Y = rg.standard_normal((T, N)) + 2.0 * Y                                                      # real-valued activity
+        model = SparseGaussianGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, a_0=2.0, b_0=2.0), seed=0, engine_kwargs=ekw)
     else:
         model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=0, engine_kwargs=ekw)
     model.add_data(Y)
@@ -159,7 +165,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s N=%d B=%d L=%d T=%d, synthetic i.i.d. %s, neurons sharded over %d GPU(s)"
-                                   % (type(model).__name__, N, B, L, T, "NB(2, 0.85) counts" if cfg.get("obs") == "negbin" else "Bernoulli(0.08) spikes", world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
+                                   % (type(model).__name__, N, B, L, T, {"negbin": "NB(2, 0.85) counts", "gaussian": "N(2 s, 1) activity"}.get(cfg.get("obs"), "Bernoulli(0.08) spikes"), world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
                        "neurons_per_batch": model.engine.nb},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
@@ -167,7 +173,14 @@ def main():
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll,
         }
-        if not args.no_cpu_baseline and world == 1 and cfg.get("obs") != "negbin":
+        if cfg.get("obs") == "gaussian":
+            # no per-neuron Gram here: X'X is formed once in add_data and only scaled per sweep (HBM-bound streaming store)
+            gs = stages.get("gram_scale", dict(ms=0.0, calls=0, work=0.0))
+            ach = gs["work"] / (gs["ms"] * 1e-3) * 1e-9 if gs["ms"] > 0 else None
+            out["roofline"] = {"bound": "hbm", "kernel": "scaled_gram_kernel (J[n] = X'X / eta_n, lower triangle)", "achieved": ach,
+                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS if ach else None, "traffic": None,
+                               "launches": gs["calls"], "avg_launch_ms": gs["ms"] / gs["calls"] if gs["calls"] else None}
+        if not args.no_cpu_baseline and world == 1 and cfg.get("obs") is None:
             out["cpu_baseline"] = cpu_baseline(model, cfg)
         else:
             out["cpu_baseline"] = None

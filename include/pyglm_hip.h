@@ -57,7 +57,17 @@ int pgl_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, 
                   uint64_t neuron0, uint64_t elem0, void* hip_stream);
 int pgl_pg_loglik_partials(int T);
 
+/* Gaussian observations (SparseGaussianRegression, pyglm/regression.py:380-446): Psi[t][n] += bias[n] (mean, :430-431); when Omega is
+ * non-NULL Omega[t][n] = inv_eta[n] (:421-423) and Kappa[t][n] = Y[t][n] * inv_eta[n] (:425-426); sse_out[n] (+)= sum_t (y - psi)^2, the
+ * statistic of both log_likelihood (:399-403) and _resample_eta (:433-445). part: scratch as for pgl_pg_loglik. */
+int pgl_gaussian_stats(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, const double* inv_eta, double* Omega, long ldo,
+                       double* Kappa, long ldk, double* part, double* sse_out, int accumulate, int T, int nloc, void* hip_stream);
+
 /* ---- likelihood statistics ------------------------------------------------------------------------------------ */
+/* J[z][i][j] = inv_eta[z] * G0[i][j] for j <= i < D (row pairs up to the diagonal): the Gaussian model's omega is constant in t, so
+ * X'OX of pyglm/regression.py:251-252 is (1/eta) X'X with X'X = G0 formed once per dataset by pgl_weighted_gram with unit weights. */
+int pgl_scaled_gram(const double* G0, long ldg, const double* inv_eta, double* J, long ldj, long strideJ, int D, int nz, void* hip_stream);
+
 /* J[z][i][j] (+)= sum_t W[t][z] * X[t][i] * X[t][j], i >= j tiles only (lower triangle valid), z in [0, nz), i,j in [0, D).
  * Replaces XO = X*omega[:,None]; J += XO.T.dot(X) at pyglm/regression.py:251-252 without the T x D temporary.
  * X: Tp x ldx (Tp % 16 == 0, rows >= T zero); W: Tp x ldw weights (rows >= T zero). */

@@ -196,11 +196,13 @@ class Regression:
     """State + conditionals of ONE postsynaptic neuron: reference `_SparseScalarRegressionBase`
     (regression.py:40-378) + `_SparsePGRegressionBase` (:459-511).  `obs` selects the observation model
     through the a/b/c hooks (:479-489):  'bernoulli' (:514-526)  a=y, b=1, c=1;
-    'negbin' (named only in the docstring :463-466)  a=y, b=y+xi, c=C(y+xi-1, y)."""
+    'negbin' (named only in the docstring :463-466)  a=y, b=y+xi, c=C(y+xi-1, y);
+    'gaussian' = `SparseGaussianRegression` (:380-446): omega = 1/eta, kappa = y/eta, eta ~ InvGamma(a_0, b_0)."""
 
-    def __init__(self, N, B, rho=0.5, mu_w=0.0, S_w=1.0, mu_b=0.0, S_b=1.0, obs="bernoulli", xi=1.0):
+    def __init__(self, N, B, rho=0.5, mu_w=0.0, S_w=1.0, mu_b=0.0, S_b=1.0, obs="bernoulli", xi=1.0, a_0=2.0, b_0=2.0, eta=1.0):
         self.N, self.B = N, B
         self.obs, self.xi = obs, xi
+        self.a_0, self.b_0, self.eta = a_0, b_0, eta
         self.set_hypers(rho, mu_w, S_w, mu_b, S_b)
         self.a = np.zeros(N, dtype=bool)
         self.W = np.zeros((N, B))
@@ -245,8 +247,24 @@ class Regression:
         return gammaln(y + self.xi) - gammaln(y + 1) - gammaln(self.xi)
 
     def kappa(self, y):
-        """regression.py:510-511"""
+        """regression.py:510-511; Gaussian :425-426"""
+        if self.obs == "gaussian":
+            return y / self.eta
         return self.a_func(y) - self.b_func(y) / 2.0
+
+    def omega_gaussian(self, T):
+        """regression.py:421-423"""
+        return 1. / self.eta * np.ones(T)
+
+    def resample_eta(self, datas, g):
+        """regression.py:433-445 with sample_invgamma(alpha, beta) = 1/gamma(alpha, scale=1/beta) and the standard Gamma(alpha, 1)
+        variate g injected.  (As in the reference, beta accumulates the FULL sum of squared residuals.)"""
+        alpha, beta = self.a_0, self.b_0
+        for X, y in datas:
+            alpha += self.flat(X).shape[0] / 2.0
+            beta += np.sum((np.asarray(y, dtype=float).reshape(-1) - self.mean(X)) ** 2)
+        self.eta = 1.0 / (g * (1.0 / beta))
+        return alpha, beta
 
     # ---- deterministic pieces
     def flat(self, X):
@@ -263,12 +281,16 @@ class Regression:
         return self.flat(X).dot(w) + self.b[0]
 
     def mean(self, X):
-        """regression.py:524-526"""
+        """regression.py:524-526; Gaussian :430-431"""
+        if self.obs == "gaussian":
+            return self.activation(X)
         return logistic(self.activation(X))
 
     def log_likelihood(self, X, y):
-        """regression.py:491-494 (per-bin vector)"""
+        """regression.py:491-494 (per-bin vector); Gaussian :399-403"""
         psi = self.activation(X)
+        if self.obs == "gaussian":
+            return -0.5 * np.log(2 * np.pi * self.eta) - 0.5 * (y - psi) ** 2 / self.eta
         return self.log_c_func(y) + self.a_func(y) * psi - self.b_func(y) * np.log1p(np.exp(psi))
 
     def natural_params(self):
@@ -465,6 +487,8 @@ class GLM:
     def omegas(self, n, seed, sweep):
         """regression.py:496-508 for neuron n on every dataset (element index continues across datasets)."""
         r = self.regressions[n]
+        if r.obs == "gaussian":
+            return [r.omega_gaussian(X.shape[0]) for X, _ in self.data_list]
         out, off = [], 0
         for X, Y in self.data_list:
             psi = r.activation(X)
@@ -472,7 +496,9 @@ class GLM:
             off += X.shape[0]
         return out
 
-    def resample_regressions(self, seed, sweep, perms, us, zs):   # models.py:169-171
+    def resample_regressions(self, seed, sweep, perms, us, zs, gs=None):   # models.py:169-171
         for n, r in enumerate(self.regressions):
             datas = [(X, Y[:, n]) for X, Y in self.data_list]
             r.resample(datas, self.omegas(n, seed, sweep), perms[n], us[n], zs[n])
+            if r.obs == "gaussian":            # SparseGaussianRegression.resample, regression.py:427-429
+                r.resample_eta(datas, gs[n])

@@ -33,6 +33,8 @@ SIGNATURES = {
     "pgl_activation": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "pgl_pg_loglik": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_u64, c_u64, c_u64, c_u64, c_p],
     "pgl_pg_loglik_partials": [c_i],
+    "pgl_gaussian_stats": [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p],
+    "pgl_scaled_gram": [c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_i, c_p],
     "pgl_weighted_gram": [c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
     "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],

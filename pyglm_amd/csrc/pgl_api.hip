@@ -18,6 +18,9 @@ int pgl_k_pg_draw(const double*, const double*, double*, size_t, uint64_t, uint6
 int pgl_k_pg_loglik(double*, long, const double*, const double*, long, double*, long, double*, long, double*, double*, int, int, int, int, double,
                     uint64_t, uint64_t, uint64_t, uint64_t, hipStream_t);
 int pgl_k_pg_loglik_nblk(int);
+int pgl_k_gaussian_stats(double*, long, const double*, const double*, long, const double*, double*, long, double*, long, double*, double*, int, int,
+                         int, hipStream_t);
+int pgl_k_scaled_gram(const double*, long, const double*, double*, long, long, int, int, hipStream_t);
 int pgl_k_basis_conv(const double*, long, const double*, double*, long, double*, long, int, int, int, int, int, hipStream_t);
 int pgl_k_transpose(const double*, long, double*, long, int, int, hipStream_t);
 int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const double*, const double*, int,
@@ -89,6 +92,17 @@ int pgl_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, 
                            elem0, ST(st));
 }
 int pgl_pg_loglik_partials(int T) { return pgl_k_pg_loglik_nblk(T); }
+
+int pgl_gaussian_stats(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, const double* inv_eta, double* Omega, long ldo,
+                       double* Kappa, long ldk, double* part, double* sse_out, int accumulate, int T, int nloc, void* st) {
+    PGL_CHECK_ARG(Psi && Y && inv_eta && part && sse_out && T > 0 && nloc > 0);
+    return pgl_k_gaussian_stats(Psi, ldpsi, bias, Y, ldy, inv_eta, Omega, ldo, Kappa, ldk, part, sse_out, accumulate, T, nloc, ST(st));
+}
+
+int pgl_scaled_gram(const double* G0, long ldg, const double* inv_eta, double* J, long ldj, long strideJ, int D, int nz, void* st) {
+    PGL_CHECK_ARG(G0 && inv_eta && J && D > 0 && nz > 0 && ldg >= D && ldj >= D && ldg % 2 == 0 && ldj % 2 == 0 && strideJ % 2 == 0);
+    return pgl_k_scaled_gram(G0, ldg, inv_eta, J, ldj, strideJ, D, nz, ST(st));
+}
 
 int pgl_weighted_gram(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ,
                       int accumulate, void* st) {

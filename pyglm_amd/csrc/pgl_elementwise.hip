@@ -41,7 +41,9 @@ struct PgLlArgs {
     double* llpart;                     // [nblk_t][nloc]
     int T, nloc;
     int obs;                            // 0 Bernoulli (a=y,b=1,c=1)  1 negative binomial (a=y, b=y+xi, c=C(y+xi-1,y))
+                                        // 2 Gaussian (regression.py:380-446): omega = 1/eta, kappa = y/eta, "ll" = sum of squared residuals
     double xi;
+    const double* inv_eta;              // [nloc] 1/eta per neuron (obs == 2 only)
     uint64_t seed, sweep, neuron0, elem0;
 };
 
@@ -60,6 +62,13 @@ __global__ __launch_bounds__(256) void pg_loglik_kernel(PgLlArgs g) {
             const double psi = g.Psi[(long)t * g.ldpsi + n] + bn;
             g.Psi[(long)t * g.ldpsi + n] = psi;
             const double y = g.Y[(long)t * g.ldy + n];
+            if (g.obs == 2) {
+                const double ie = g.inv_eta[n], r = y - psi;
+                ll += r * r;
+                if (g.Kappa) g.Kappa[(long)t * g.ldk + n] = y * ie;
+                if (g.Omega) g.Omega[(long)t * g.ldo + n] = ie;
+                continue;
+            }
             double a = y, b = 1.0, logc = 0.0;
             if (g.obs == 1) { b = y + g.xi; logc = lgamma(y + g.xi) - lgamma(y + 1.0) - lgamma(g.xi); }
             ll += logc + a * psi - b * log1p(exp(psi));
@@ -173,6 +182,29 @@ __global__ __launch_bounds__(256) void assemble_post_kernel(PostArgs g) {
     }
 }
 
+// ------------------------------------------------------------------ Gaussian observations: J_lkhd[n] = (1/eta_n) X'X
+// omega is the constant 1/eta_n (regression.py:421-423), so the Gram X'X is formed once per dataset and every sweep only
+// scales it per neuron.  Each thread reads one pair of G0 and streams it to the nb neuron slots (coalesced 16-B stores);
+// the lower triangle is what the later stages read, the pass covers whole rows up to the diagonal pair.
+struct ScaleArgs {
+    const double* G0; long ldg;
+    const double* inv_eta;
+    double* J; long ldj; long strideJ;
+    int D, nb;
+};
+
+__global__ __launch_bounds__(256) void scaled_gram_kernel(ScaleArgs g) {
+    const int r = blockIdx.y;
+    const int c = 2 * (blockIdx.x * 256 + threadIdx.x);
+    if (c > r || c >= g.D) return;
+    const double2 v = *reinterpret_cast<const double2*>(g.G0 + (long)r * g.ldg + c);
+    double* dst = g.J + (long)r * g.ldj + c;
+    for (int n = 0; n < g.nb; ++n) {
+        const double ie = g.inv_eta[n];
+        *reinterpret_cast<double2*>(dst + (long)n * g.strideJ) = make_double2(v.x * ie, v.y * ie);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host launchers (called from pgl_api.hip)
@@ -193,11 +225,29 @@ int pgl_k_pg_draw(const double* b, const double* z, double* out, size_t len, uin
 int pgl_k_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, double* Omega, long ldo, double* Kappa, long ldk,
                     double* llpart, double* ll_out, int accumulate, int T, int nloc, int obs, double xi, uint64_t seed, uint64_t sweep,
                     uint64_t neuron0, uint64_t elem0, hipStream_t st) {
-    PgLlArgs a{Psi, ldpsi, bias, Y, ldy, Omega, ldo, Kappa, ldk, llpart, T, nloc, obs, xi, seed, sweep, neuron0, elem0};
+    PgLlArgs a{Psi, ldpsi, bias, Y, ldy, Omega, ldo, Kappa, ldk, llpart, T, nloc, obs, xi, nullptr, seed, sweep, neuron0, elem0};
     const int nblk = (T + PGLL_ROWS - 1) / PGLL_ROWS;
     hipLaunchKernelGGL(pg_loglik_kernel, dim3(nblk, (nloc + 63) / 64), dim3(256), 0, st, a);
     PGL_CHECK_LAUNCH();
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, llpart, nblk, nloc, ll_out, accumulate);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_gaussian_stats(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, const double* inv_eta, double* Omega, long ldo,
+                         double* Kappa, long ldk, double* part, double* sse_out, int accumulate, int T, int nloc, hipStream_t st) {
+    PgLlArgs a{Psi, ldpsi, bias, Y, ldy, Omega, ldo, Kappa, ldk, part, T, nloc, 2, 1.0, inv_eta, 0, 0, 0, 0};
+    const int nblk = (T + PGLL_ROWS - 1) / PGLL_ROWS;
+    hipLaunchKernelGGL(pg_loglik_kernel, dim3(nblk, (nloc + 63) / 64), dim3(256), 0, st, a);
+    PGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, part, nblk, nloc, sse_out, accumulate);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_scaled_gram(const double* G0, long ldg, const double* inv_eta, double* J, long ldj, long strideJ, int D, int nb, hipStream_t st) {
+    ScaleArgs a{G0, ldg, inv_eta, J, ldj, strideJ, D, nb};
+    hipLaunchKernelGGL(scaled_gram_kernel, dim3((D / 2 + 255) / 256 + 1, D), dim3(256), 0, st, a);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

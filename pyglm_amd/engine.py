@@ -37,6 +37,16 @@ def make_draws(seed, sweep, neuron_ids, N, D):
     return perm, u, z
 
 
+def make_gamma_draws(seed, sweep, neuron_ids, alpha):
+    """standard Gamma(alpha, 1) variates for the noise-variance update of the Gaussian model (regression.py:433-445), keyed like
+    make_draws by (seed, sweep, GLOBAL neuron) on a separate counter lane"""
+    g = np.empty(len(neuron_ids))
+    for i, n in enumerate(neuron_ids):
+        rng = np.random.Generator(np.random.Philox(key=int(seed) & (2 ** 64 - 1), counter=[int(sweep), int(n), 1, 0]))
+        g[i] = rng.standard_gamma(alpha)
+    return g
+
+
 def prior_terms(S_w, mu_w, S_b, mu_b):
     """natural parameters (regression.py:138-151) + the per-block prior constant of the collapsed flips.
     S_w (n,N,B,B), mu_w (n,N,B), S_b (n,), mu_b (n,)  ->  Jw, hw, Jb, hb, c0 (n,N)."""
@@ -54,7 +64,7 @@ class _Dataset(object):
 
 
 class GibbsEngine(object):
-    OBS = {"bernoulli": 0, "negbin": 1}
+    OBS = {"bernoulli": 0, "negbin": 1, "gaussian": 2}
 
     def __init__(self, N, B, n0=0, n1=None, device="cuda:0", obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None,
                  design_only=False):
@@ -148,6 +158,11 @@ class GibbsEngine(object):
         self.bias = self._z(nl)
         self.border = self._z(2 * self.ldn, self.Dp)
         self.ll = self._z(nl)
+        if self.obs == 2:
+            # Gaussian observations: omega = 1/eta is constant in t, so X'X is formed once per dataset (add_data) and scaled per sweep
+            self.G0 = self._z(self.ldj, self.ldj)
+            self.inv_eta = torch.ones(nl, dtype=F64, device=self.dev)
+            self.eta = np.ones(nl)
 
     def _st(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -188,7 +203,19 @@ class GibbsEngine(object):
         ds.Psi = self._z(T, self.ldn)
         ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
         ds.llpart = self._z(_lib.load().pgl_pg_loglik_partials(T), self.nloc)
+        if self.obs == 2:
+            ones = self._z(ds.Tp, 2)
+            ones[:T, 0] = 1.0
+            call("pgl_weighted_gram", ptr(ds.X), self.Dp, self.Dp, ptr(ones), 2, ds.Tp, self.D, 1, ptr(self.G0), self.ldj, self.ldj * self.ldj,
+                 int(len(self.datasets) > 1), st)
+            torch.cuda.synchronize(self.dev)
         return ds
+
+    def set_noise(self, eta):
+        """noise variances eta (nloc,) of the Gaussian observation model (regression.py:380-398)"""
+        assert self.obs == 2
+        self.eta = np.asarray(eta, dtype=np.float64).reshape(self.nloc).copy()
+        self.inv_eta.copy_(torch.from_numpy(1.0 / self.eta))
 
     def design_matrix(self, i=0):
         ds = self.datasets[i]
@@ -212,6 +239,11 @@ class GibbsEngine(object):
             h = self._tic("pg_loglik", float(ds.T) * self.nloc)
             om = ds.OK if draw else None
             kp = ctypes.c_void_p(ds.OK.data_ptr() + 8 * self.ldn) if draw else None
+            if self.obs == 2:      # self.ll then holds the sums of squared residuals
+                call("pgl_gaussian_stats", ptr(ds.Psi), self.ldn, ptr(self.bias), ptr(ds.Y), self.ldn, ptr(self.inv_eta), ptr(om), 2 * self.ldn,
+                     kp, 2 * self.ldn, ptr(ds.llpart), ptr(self.ll), int(i > 0), ds.T, self.nloc, st)
+                self._toc(h)
+                continue
             call("pgl_pg_loglik", ptr(ds.Psi), self.ldn, ptr(self.bias), ptr(ds.Y), self.ldn, ptr(om), 2 * self.ldn, kp, 2 * self.ldn,
                  ptr(ds.llpart), ptr(self.ll), int(i > 0), ds.T, self.nloc, self.obs, self.xi, int(seed), int(sweep), self.n0, ds.elem0, st)
             self._toc(h)
@@ -219,6 +251,19 @@ class GibbsEngine(object):
 
     def log_likelihood(self, a, W, b):
         """per-neuron sum_t log p(y_t | psi_t) (regression.py:491-494 summed as at models.py:93-94)."""
+        self._upload_weights(a, W, b)
+        return self._ll_host(self._psi_pass(False, 0, 0))
+
+    def _ll_host(self, ll_dev):
+        ll = ll_dev.cpu().numpy().copy()
+        if self.obs == 2:          # regression.py:399-403 summed over t: -T/2 log(2 pi eta) - sse / (2 eta)
+            T = sum(ds.T for ds in self.datasets)
+            ll = -0.5 * T * np.log(2 * np.pi * self.eta) - 0.5 * ll / self.eta
+        return ll
+
+    def sse(self, a, W, b):
+        """sum_t (y - mean)^2 per local neuron, the statistic of _resample_eta (regression.py:433-445)"""
+        assert self.obs == 2
         self._upload_weights(a, W, b)
         return self._psi_pass(False, 0, 0).cpu().numpy().copy()
 
@@ -240,7 +285,7 @@ class GibbsEngine(object):
         det = np.all((rho < 1e-6) | (rho > 1 - 1e-6), axis=1)           # regression.py:153-155
         self._upload_weights(a, W, b)
         self._psi_pass(True, seed, sweep)
-        ll_before = self.ll.cpu().numpy().copy()
+        ll_before = self._ll_host(self.ll)
         if omega_override is not None:
             for ds, om in zip(self.datasets, omega_override):
                 ds.OK[:ds.T, :nloc] = torch.from_numpy(np.ascontiguousarray(om, dtype=np.float64)).to(self.dev)
@@ -280,6 +325,11 @@ class GibbsEngine(object):
         D, ldn, Dp, ldj = self.D, self.ldn, self.Dp, self.ldj
         st = self._st()
         J = self.Jslots[slot]
+        if self.obs == 2:
+            h = self._tic("gram_scale", 8.0 * nbb * D * (D + 1) / 2)
+            call("pgl_scaled_gram", ptr(self.G0), ldj, ctypes.c_void_p(self.inv_eta.data_ptr() + 8 * s), ptr(J), ldj, ldj * ldj, D, nbb, st)
+            self._toc(h)
+            return
         for i, ds in enumerate(self.datasets):
             h = self._tic("gram", float(nbb) * ds.T * D * (D + 1))     # algorithmic flops: lower triangle, 2 flop per MAC
             call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * s), 2 * ldn, ds.Tp, D, nbb, ptr(J), ldj,

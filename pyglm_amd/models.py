@@ -140,13 +140,16 @@ class NonlinearAutoregressiveModel(object):
             eng = self.engine
         else:
             from .engine import GibbsEngine
-            eng = (self._engine_factory or GibbsEngine)(self.N, self.B, self.n0, self.n1, obs=self.engine_obs())
+            eng = (self._engine_factory or GibbsEngine)(self.N, self.B, self.n0, self.n1, obs=self.engine_obs(),
+                                                               xi=getattr(self.regressions[0], "xi", 1.0))
             for d in datas:
                 if isinstance(d, tuple):
                     eng.add_data(d[1], X=d[0] if not isinstance(d[0], _LazyX) else None, basis=self.basis)
                 else:
                     eng.add_data(d, basis=self.basis)
         a, W, b = self._local_state()
+        if self.engine_obs() == "gaussian":
+            eng.set_noise([r.eta for r in self.regressions[self.n0:self.n1]])
         ll = float(np.sum(eng.log_likelihood(a, W, b)))
         dist = _dist()
         if dist is not None:
@@ -168,7 +171,8 @@ class NonlinearAutoregressiveModel(object):
         mus = []
         for i in range(len(self.data_list)):
             psi = self.engine.psi(a, W, b, i)
-            mu = logistic(psi) if self.engine_obs() == "bernoulli" else self.regressions[0].xi * np.exp(psi)
+            obs = self.engine_obs()
+            mu = logistic(psi) if obs == "bernoulli" else psi if obs == "gaussian" else self.regressions[0].xi * np.exp(psi)
             mus.append(self._gather_rows(np.ascontiguousarray(mu.T)).T)
         return mus
 
@@ -217,13 +221,29 @@ class NonlinearAutoregressiveModel(object):
             Jw, hw, Jb, hb, c0 = prior_terms(S_w, mu_w, S_b, mu_b)
             self._hyper_cache = (versions, (rho, Jw, hw, Jb, hb, c0))
         perm, u, z = make_draws(self.seed, self.sweeps_done, range(self.n0, self.n1), self.N, self.N * self.B)
+        gaussian = self.engine_obs() == "gaussian"
+        if gaussian:
+            self.engine.set_noise([r.eta for r in regs])
         a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done)
+        if gaussian:
+            # noise variances (regression.py:433-445): residual sums of squares under the NEW weights from the device, gamma draws
+            # keyed by the global neuron index
+            from .engine import make_gamma_draws
+            T_total = sum(d[1].shape[0] for d in self.data_list)
+            sse = self.engine.sse(a, W, b)
+            eta = np.empty(len(regs))
+            for i, r in enumerate(regs):
+                alpha, beta = r.eta_posterior(T_total, sse[i])
+                eta[i] = 1.0 / (make_gamma_draws(self.seed, self.sweeps_done, [self.n0 + i], alpha)[0] * (1.0 / beta))
+            eta_all = self._gather_rows(eta)
         self.sweeps_done += 1
         A_all = self._gather_rows(a)
         W_all = self._gather_rows(W)
         b_all = self._gather_rows(b)
         for n, r in enumerate(self.regressions):
             r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
+            if gaussian:
+                r.eta = float(eta_all[n])
 
     def plot(self, *args, **kwargs):
         raise NotImplementedError("plotting is outside the scope of the MI355X hot path (SURVEY.md section 2, row 8)")
@@ -330,6 +350,18 @@ class _DefaultMixin(object):
         if regressions is None:
             regressions = [self._regression_class(N, B, **(regression_kwargs or {})) for _ in range(N)]
         super(_DefaultMixin, self).__init__(N, network, regressions, B=B, basis=basis, **kw)
+
+
+class GaussianGLM(_DefaultMixin, NetworkGLM):
+    """(models.py:270-272)"""
+    _network_class = _networks.NIWDenseNetwork
+    _regression_class = _regression.GaussianRegression
+
+
+class SparseGaussianGLM(_DefaultMixin, NetworkGLM):
+    """(models.py:274-276)"""
+    _network_class = _networks.NIWSparseNetwork
+    _regression_class = _regression.SparseGaussianRegression
 
 
 class BernoulliGLM(_DefaultMixin, NetworkGLM):

@@ -100,6 +100,12 @@ class _SparseScalarRegressionBase(object):
         eng = self._engine([(X, np.zeros(X.shape[0]))])
         return eng.psi(self.a[None], self.W[None], self.b)[:, 0]
 
+    def _before_sweep(self, eng):
+        pass
+
+    def _after_sweep(self, eng, seed, sweep):
+        pass
+
     def resample(self, datas, seed=None, sweep=0):
         """One Gibbs update of (a, W, b) given datasets [(X, y), ...]  (:265-280)."""
         from .engine import make_draws, prior_terms
@@ -107,8 +113,70 @@ class _SparseScalarRegressionBase(object):
         seed = int(npr.randint(2 ** 31)) if seed is None else seed
         Jw, hw, Jb, hb, c0 = prior_terms(self.S_w[None], self.mu_w[None], self.S_b.reshape(1), self.mu_b.reshape(1))
         perm, u, z = make_draws(seed, sweep, [0], self.N, self.N * self.B)
+        self._before_sweep(eng)
         a, W, b, _ = eng.sweep(self.a[None], self.W[None], self.b, self.rho[None], Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep)
         self.a, self.W, self.b = a[0], W[0], b.reshape(1)
+        self._after_sweep(eng, seed, sweep)
+
+
+class SparseGaussianRegression(_SparseScalarRegressionBase):
+    """y_t ~ N(psi_t, eta), eta ~ InvGamma(a_0, b_0)  (reference regression.py:380-446).  omega = 1/eta is constant in t, so on the GPU
+    the likelihood precision is (1/eta) X'X with X'X formed once per dataset (engine.add_data) instead of one Gram per neuron."""
+    _obs = "gaussian"
+
+    def __init__(self, N, B, a_0=2.0, b_0=2.0, eta=None, **kwargs):
+        super(SparseGaussianRegression, self).__init__(N, B, **kwargs)
+        assert np.isscalar(a_0) and a_0 > 0
+        assert np.isscalar(b_0) and a_0 > 0
+        self.a_0, self.b_0 = a_0, b_0
+        if eta is not None:
+            assert np.isscalar(eta) and eta > 0
+            self.eta = eta
+        else:
+            self.eta = 1.0 / npr.gamma(self.a_0, 1.0 / self.b_0)      # sample_invgamma(a_0, b_0)  (:396-398)
+
+    def mean(self, X):
+        return self.activation(X)
+
+    def log_likelihood(self, x):
+        """per-bin log N(y_t | mean_t, eta)  (:399-403)"""
+        X, y = self.extract_data(x)
+        return -0.5 * np.log(2 * np.pi * self.eta) - 0.5 * (y - self.mean(X)) ** 2 / self.eta
+
+    def rvs(self, size=[], X=None, psi=None):
+        if psi is None:
+            if X is None:
+                assert isinstance(size, int)
+                X = npr.randn(size, self.N * self.B)
+            psi = self.mean(self._flatten_X(X))
+        return psi + np.sqrt(self.eta) * npr.randn(*psi.shape)
+
+    def omega(self, X, y):
+        return 1.0 / self.eta * np.ones(X.shape[0])
+
+    def kappa(self, X, y):
+        return y / self.eta
+
+    def eta_posterior(self, T_total, sse):
+        """(alpha, beta) of the conditional of eta (:433-445; the reference adds the full sum of squares, not half of it)"""
+        return self.a_0 + T_total / 2.0, self.b_0 + sse
+
+    def _before_sweep(self, eng):
+        eng.set_noise([self.eta])
+
+    def _after_sweep(self, eng, seed, sweep):
+        from .engine import make_gamma_draws
+        T_total = sum(ds.T for ds in eng.datasets)
+        alpha, beta = self.eta_posterior(T_total, float(eng.sse(self.a[None], self.W[None], self.b)[0]))
+        self.eta = 1.0 / (make_gamma_draws(seed, sweep, [0], alpha)[0] * (1.0 / beta))
+
+
+class GaussianRegression(SparseGaussianRegression):
+    """dense weights: rho = 1 (:448-456)"""
+
+    def __init__(self, N, B, **kwargs):
+        kwargs["rho"] = np.ones(N)
+        super(GaussianRegression, self).__init__(N, B, **kwargs)
 
 
 class _SparsePGRegressionBase(_SparseScalarRegressionBase):

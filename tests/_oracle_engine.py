@@ -15,6 +15,17 @@ class OracleEngine(object):
         self.datasets = []
         self.nb = self.nloc
         self.profile = False
+        self.eta = np.ones(self.nloc)
+
+    def set_noise(self, eta):
+        self.eta = np.asarray(eta, float).reshape(self.nloc).copy()
+
+    def sse(self, a, W, b):
+        out = np.zeros(self.nloc)
+        for i in range(self.nloc):
+            r = self._reg(a, W, b, i)
+            out[i] = sum(np.sum((Y[:, self.n0 + i] - r.mean(X)) ** 2) for X, Y in self.datasets)
+        return out
 
     def add_data(self, Y, X=None, basis=None):
         if X is None:
@@ -25,7 +36,7 @@ class OracleEngine(object):
         return self.datasets[i][0]
 
     def _reg(self, a, W, b, i, **hyp):
-        r = orc.Regression(self.N, self.B, obs=self.obs, xi=self.xi, **hyp)
+        r = orc.Regression(self.N, self.B, obs=self.obs, xi=self.xi, eta=self.eta[i], **hyp)
         r.a, r.W, r.b = np.asarray(a[i]).astype(bool).copy(), np.asarray(W[i], float).copy(), np.atleast_1d(np.asarray(b, float)[i]).copy()
         return r
 
@@ -50,6 +61,9 @@ class OracleEngine(object):
             datas, oms, off = [], [], 0
             for X, Y in self.datasets:
                 datas.append((X, Y[:, n]))
+                if self.obs == "gaussian":
+                    oms.append(r.omega_gaussian(X.shape[0]))
+                    continue
                 oms.append(orc.pg_draw(r.b_func(Y[:, n]), r.activation(X), seed, orc.stream_id(n, sweep), off))
                 off += X.shape[0]
             r.resample(datas, oms, perm[i], u[i], z[i])

@@ -18,6 +18,13 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden_gauss():
+    """SparseGaussianRegression / SparseGaussianGLM vectors (tests/golden/make_fixtures.py::main_gaussian)"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors_gaussian.npz"))
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_oracle():
     """The oracle's C restatement is test infrastructure; build it on demand (gcc only)."""

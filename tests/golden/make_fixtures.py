@@ -37,6 +37,8 @@ class Tape:
         self.normals = []      # consumed by sample_gaussian
         self.used_u = []
         self.used_z = []
+        self.gammas = []       # consumed by sample_invgamma
+        self.used_g = []
 
 
 TAPE = Tape()
@@ -75,6 +77,12 @@ def _install_shims():
         return sla.solve_triangular(L, z, lower=True, trans="T") + sla.lapack.dpotrs(L, h, lower=True)[0]
 
     def sample_invgamma(alpha, beta):
+        # published definition: 1 / Gamma(shape alpha, scale 1/beta); the standard Gamma(alpha, 1) variate is taken from the tape
+        # when one is queued (recorded in the fixture), else from NumPy's global generator
+        if TAPE.gammas:
+            g = TAPE.gammas.pop(0)
+            TAPE.used_g.append((alpha, beta, g))
+            return 1.0 / (g * (1.0 / beta))
         return 1.0 / np.random.gamma(alpha, 1.0 / beta)
 
     stats.sample_discrete_from_log = sample_discrete_from_log
@@ -299,5 +307,109 @@ def main():
     print("wrote", path, "%d arrays, %.1f KB" % (len(out), os.path.getsize(path) / 1024))
 
 
+def main_gaussian():
+    """SparseGaussianRegression / GaussianRegression (regression.py:380-456) and SparseGaussianGLM (models.py:274-276):
+    written to a second file so that reference_vectors.npz stays byte-stable."""
+    import numpy.random as npr
+    from pyglm.regression import SparseGaussianRegression, GaussianRegression
+    from pyglm.models import SparseGaussianGLM
+    from pyglm.utils.basis import cosine_basis
+    import pyglm.regression as refreg
+
+    rng = np.random.default_rng(20240917)
+    out = {}
+    cases = [
+        dict(tag="g0", cls=SparseGaussianRegression, N=4, B=2, T=300, kw=dict(rho=0.5, S_w=4.0, mu_b=0.5, S_b=2.0, a_0=2.0, b_0=2.0)),
+        dict(tag="g1", cls=SparseGaussianRegression, N=6, B=3, T=400, kw=dict(rho=0.3, S_w=1.5, mu_w=0.2, a_0=3.0, b_0=1.0, eta=0.37)),
+        dict(tag="g2", cls=GaussianRegression, N=3, B=2, T=250, kw=dict(S_w=2.0, a_0=2.5, b_0=0.5)),     # dense: rho = 1
+    ]
+    for c in cases:
+        tag, N, B, T = c["tag"], c["N"], c["B"], c["T"]
+        np.random.seed(23)
+        reg = c["cls"](N, B, **c["kw"])
+        X = rng.standard_normal((T, N, B)) * 0.5
+        wtrue = rng.standard_normal(N * B) * (rng.random(N * B) < 0.6)
+        y = X.reshape(T, -1).dot(wtrue) + 0.3 + 0.7 * rng.standard_normal(T)
+        X2 = rng.standard_normal((T // 3, N, B)) * 0.5
+        y2 = X2.reshape(T // 3, -1).dot(wtrue) + 0.3 + 0.7 * rng.standard_normal(T // 3)
+        out[tag + "_rho"], out[tag + "_mu_w"], out[tag + "_S_w"] = reg.rho.copy(), reg.mu_w.copy(), reg.S_w.copy()
+        out[tag + "_mu_b"], out[tag + "_S_b"] = reg.mu_b.copy(), reg.S_b.copy()
+        out[tag + "_a_0"], out[tag + "_b_0"], out[tag + "_eta0"] = np.array(reg.a_0), np.array(reg.b_0), np.array(reg.eta)
+        out[tag + "_X"], out[tag + "_y"], out[tag + "_X2"], out[tag + "_y2"] = X, y, X2, y2
+        out[tag + "_a0"], out[tag + "_W0"], out[tag + "_b0"] = reg.a.copy(), reg.W.copy(), reg.b.copy()
+        out[tag + "_psi"], out[tag + "_mean"] = reg.activation(X), reg.mean(X)
+        out[tag + "_omega"], out[tag + "_kappa"] = reg.omega(X, y), reg.kappa(X, y)
+        out[tag + "_ll"] = reg.log_likelihood((X, y))
+        Jl, hl = reg._lkhd_sufficient_statistics([(X, y), (X2, y2)])
+        out[tag + "_J_lkhd"], out[tag + "_h_lkhd"] = Jl, hl
+        perm = rng.permutation(N)
+        u = rng.random(N)
+        z = rng.standard_normal(N * B + 1)
+        g = rng.standard_gamma(reg.a_0 + (T + T // 3) / 2.0)
+        orig_perm = npr.permutation
+        refreg.npr.permutation = lambda n: perm.copy()
+        TAPE.uniforms = list(u)
+        TAPE.used_u, TAPE.used_z, TAPE.used_g = [], [], []
+        TAPE.gammas = [g]
+
+        class LazyNormals(object):
+            def pop(self, i=0):
+                return z[: int(reg.a.sum()) * B + 1].copy()
+        TAPE.normals = LazyNormals()
+        reg.resample([(X, y), (X2, y2)])
+        refreg.npr.permutation = orig_perm
+        assert len(TAPE.used_g) == 1
+        out[tag + "_perm"], out[tag + "_u"], out[tag + "_z"], out[tag + "_g"] = perm, u, z, np.array(g)
+        out[tag + "_alpha1"], out[tag + "_beta1"] = np.array(TAPE.used_g[0][0]), np.array(TAPE.used_g[0][1])
+        out[tag + "_a1"], out[tag + "_W1"], out[tag + "_b1"], out[tag + "_eta1"] = reg.a.copy(), reg.W.copy(), reg.b.copy(), np.array(reg.eta)
+        out[tag + "_ll1"] = reg.log_likelihood((X, y)).sum()
+
+    # model level: SparseGaussianGLM, two sweeps of the regressions with injected randomness
+    np.random.seed(5)
+    N, B, L, T = 4, 2, 15, 500
+    basis = cosine_basis(B, L=L) / L
+    glm = SparseGaussianGLM(N, basis=basis, regression_kwargs=dict(S_w=5.0, a_0=2.0, b_0=1.0))
+    Y = rng.standard_normal((T, N))
+    for t in range(1, T):
+        Y[t] += 0.5 * Y[t - 1, ::-1]
+    glm.add_data(Y)
+    out["MG_basis"], out["MG_Y"], out["MG_X"] = basis, Y, glm.data_list[0][0]
+    out["MG_A0"], out["MG_W0"], out["MG_b0"] = glm.adjacency.copy(), glm.weights.copy(), glm.biases.copy()
+    out["MG_eta0"] = np.array([r.eta for r in glm.regressions])
+    out["MG_ll0"] = np.array(glm.log_likelihood())
+    out["MG_means0"] = glm.means[0]
+    nsw = 2
+    perms = np.array([[rng.permutation(N) for _ in range(N)] for _ in range(nsw)])
+    us = rng.random((nsw, N, N))
+    zs = rng.standard_normal((nsw, N, N * B + 1))
+    gs = rng.standard_gamma(2.0 + T / 2.0, size=(nsw, N))
+    out["MG_perms"], out["MG_us"], out["MG_zs"], out["MG_gs"] = perms, us, zs, gs
+    state = dict(n=0, s=0)
+    orig_perm = npr.permutation
+    refreg.npr.permutation = lambda nn: perms[state["s"], state["n"]].copy()
+
+    class ModelNormals(object):
+        def pop(self, i=0):
+            r = glm.regressions[state["n"]]
+            return zs[state["s"], state["n"], : int(r.a.sum()) * B + 1].copy()
+    TAPE.normals = ModelNormals()
+    for sw in range(nsw):
+        for n, reg in enumerate(glm.regressions):
+            state["n"], state["s"] = n, sw
+            TAPE.uniforms = list(us[sw, n])
+            TAPE.gammas = [gs[sw, n]]
+            reg.resample([(X_, Y_[:, n]) for (X_, Y_) in glm.data_list])
+        out["MG_A%d" % (sw + 1)], out["MG_W%d" % (sw + 1)] = glm.adjacency.copy(), glm.weights.copy()
+        out["MG_b%d" % (sw + 1)] = glm.biases.copy()
+        out["MG_eta%d" % (sw + 1)] = np.array([r.eta for r in glm.regressions])
+        out["MG_ll%d" % (sw + 1)] = np.array(glm.log_likelihood())
+    refreg.npr.permutation = orig_perm
+
+    path = os.path.join(OUT, "reference_vectors_gaussian.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%d arrays, %.1f KB" % (len(out), os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     main()
+    main_gaussian()
