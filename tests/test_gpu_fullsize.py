@@ -1,6 +1,6 @@
 """Full-size GPU checks through size-independent properties (the oracle cannot finish these sizes in seconds):
 BASELINE.json configs[1] (N=128, B=5, T=50000) end to end, configs[2]-shaped (D=5120, T=100000) per-kernel identities,
-and a maximum-size dense case (D=16384) for the Cholesky path."""
+a maximum-size dense case (D=16384) for the Cholesky path, and configs[4]-shaped (D=32768, T=200000) sweeps with flips."""
 import ctypes
 
 import numpy as np
@@ -133,3 +133,50 @@ def test_dense_maximum_size_cholesky_path():
     d = torch.from_numpy(np.concatenate((W2[1].ravel(), [b2[1]]))).cuda() - mu
     q = (d @ (Jfull @ d)).item()
     assert abs(q - float(z[1] @ z[1])) <= 1e-7 * float(z[1] @ z[1])
+
+
+def test_cfg5_shape_sweep_with_flips():
+    """BASELINE.json configs[4] shape (N=4096, B=8, T=200000: D=32768, 157 GB resident) for two local neurons with a ~50 % dense
+    chain: the final sweep tableau against its definition (M_SS = -J_SS^-1 on a probe vector) and the weight draw against an
+    independent torch fp64 Cholesky solve ((x - mu)' J_SS (x - mu) = z'z on a ~16000-dimensional active system)."""
+    import gc
+    import torch
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    gc.collect()
+    torch.cuda.empty_cache()
+    N, B, T, nloc = 4096, 8, 200000, 2
+    basis, Y, rng = _problem(N, B, T)
+    eng = GibbsEngine(N, B, 0, nloc, batch=nloc)
+    eng.add_data(Y, basis=basis)
+    a = rng.random((nloc, N)) < 0.5
+    W = rng.standard_normal((nloc, N, B)) * 0.05 * a[:, :, None]
+    b = np.full(nloc, -2.0)
+    # a tight slab (S_w = 1e-3 I) makes the flip log-odds ~ logit(rho): the chain stays about half dense
+    hyp = prior_terms(np.tile(np.eye(B) * 1e-3, (nloc, N, 1, 1)), np.zeros((nloc, N, B)), np.ones(nloc), np.full(nloc, -2.0))
+    perm, u, z = make_draws(5, 0, range(nloc), N, N * B)
+    a1, W1, b1, _ = eng.sweep(a, W, b, np.full((nloc, N), 0.5), *hyp, perm, u, z, seed=5, sweep=0)
+    D = N * B
+    assert np.all(W1[~a1] == 0) and 0.3 * N < a1[0].sum() < 0.7 * N and not np.array_equal(a1, a)
+    for i in range(nloc):
+        M = torch.tril(eng.Jbuf[i, :D + 2, :D + 2])
+        m = torch.from_numpy(np.concatenate((np.repeat(a1[i], B), [True]))).cuda()
+        idx = torch.nonzero(m)[:, 0]
+        k = idx.numel()
+        Js = M[:D + 1, :D + 1][idx][:, idx]
+        Js = Js + torch.tril(Js, -1).t()
+        h = M[D + 1, :D + 1][idx]
+        del M
+        mu = torch.cholesky_solve(h[:, None], torch.linalg.cholesky(Js))[:, 0]
+        d = torch.from_numpy(np.concatenate((W1[i][a1[i]].ravel(), [b1[i]]))).cuda() - mu
+        zz = float(z[i, :k] @ z[i, :k])
+        assert abs((d @ (Js @ d)).item() / zz - 1) < 1e-8
+        low = torch.tril(eng.Mtab[i, :D + 1, :D + 1])
+        Ms = low[idx][:, idx]
+        del low
+        Ms = Ms + torch.tril(Ms, -1).t()
+        v = torch.from_numpy(np.random.default_rng(3).standard_normal(k)).cuda()
+        assert (Js @ (Ms @ v) + v).abs().max().item() < 1e-8 * v.abs().max().item()
+        del Js, Ms
+    del eng
+    gc.collect()
+    torch.cuda.empty_cache()
