@@ -103,6 +103,9 @@ typedef struct {
 int pgl_flip_kmax(void);                         /* pivots (scalar rows) per tableau update */
 int pgl_flip_window_blocks(int B);               /* blocks proposed per window */
 int pgl_flip_apply(const pgl_flip_t* s, void* hip_stream);              /* sweep the tableau on the listed pivots (<= 128 per call is fast) */
+/* same for lists of up to max_pivots <= 256 rows per neuron that are all switched ON (the pivot block is positive definite): the
+ * initial sweep on the active set; the 256 x 256 pivot-block inverse is assembled from two in-LDS 128 x 128 inversions. Uses Lws. */
+int pgl_flip_apply_chunk(const pgl_flip_t* s, int max_pivots, void* hip_stream);
 int pgl_flip_apply_window(const pgl_flip_t* s, void* hip_stream);       /* same, right after pgl_flip_decide (which already left G = (M_DD)^-1) */
 int pgl_flip_decide(const pgl_flip_t* s, int window, void* hip_stream); /* run one window of proposals; fills the pivot list */
 

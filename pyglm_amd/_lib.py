@@ -41,6 +41,7 @@ SIGNATURES = {
     "pgl_flip_kmax": [],
     "pgl_flip_window_blocks": [c_i],
     "pgl_flip_apply": [ctypes.POINTER(FlipState), c_p],
+    "pgl_flip_apply_chunk": [ctypes.POINTER(FlipState), c_i, c_p],
     "pgl_flip_apply_window": [ctypes.POINTER(FlipState), c_p],
     "pgl_flip_decide": [ctypes.POINTER(FlipState), c_i, c_p],
     "pgl_active_index": [ctypes.POINTER(CholState), c_p],

@@ -30,7 +30,7 @@ struct PglFlipState {
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
 };
-int pgl_k_flip_apply(const PglFlipState&, int, hipStream_t);
+int pgl_k_flip_apply(const PglFlipState&, int, int, hipStream_t);
 int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);
 int pgl_k_flip_kmax(void);
 int pgl_k_flip_window_blocks(int);
@@ -145,12 +145,17 @@ int pgl_flip_window_blocks(int B) { return pgl_k_flip_window_blocks(B); }
 int pgl_flip_apply(const pgl_flip_t* s, void* st) {
     PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Ut && s->Wt && s->status);
     PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0);
-    return pgl_k_flip_apply(to_state(s), 0, ST(st));
+    return pgl_k_flip_apply(to_state(s), 0, 128, ST(st));
+}
+int pgl_flip_apply_chunk(const pgl_flip_t* s, int max_pivots, void* st) {
+    PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Lws && s->Ut && s->Wt && s->status);
+    PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0 && max_pivots > 0);
+    return pgl_k_flip_apply(to_state(s), 0, max_pivots, ST(st));
 }
 int pgl_flip_apply_window(const pgl_flip_t* s, void* st) {
     PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Ut && s->Wt && s->status);
     PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0);
-    return pgl_k_flip_apply(to_state(s), 1, ST(st));
+    return pgl_k_flip_apply(to_state(s), 1, 0, ST(st));
 }
 int pgl_flip_decide(const pgl_flip_t* s, int window, void* st) {
     PGL_CHECK_ARG(s && s->M && s->perm && s->u && s->rho && s->c0 && s->a && s->d_idx && s->d_sign && s->d_cnt && s->status && s->Lws);

@@ -271,6 +271,92 @@ __global__ __launch_bounds__(256) void invert_kernel(FlipArgs g) {
     if (tid == 0) { g.batch_k[n] = (k + 15) & ~15; if (s_bad) atomicOr(&g.status[n], 2); }
 }
 
+// ------------------------------------------------------------------ pivot lists of 129..256 rows: G by 2 x 2 blocks of 128
+// (the initial sweep on the active set is cheaper per pivot with rank-256 updates: the tableau is read and written once per 256
+// pivots and the update becomes MFMA-bound; the 256 x 256 inverse is assembled from two in-LDS 128 x 128 inversions and five
+// 128^3 products on the MFMA kernel)   with T = G_A M_AB, S = M_BB - M_BA T:
+//     G_BB = S^-1,   G_BA = -S^-1 T',   G_AA = G_A + T S^-1 T' = G_A - G_BA' T'
+constexpr int KB2 = 128;            // block size
+// Akk[i][j] = M[idx[i]][idx[j]] for i, j < k, identity elsewhere in the 256 x 256 frame (so the fixed-size block products and
+// inversions need no per-neuron sizes)
+__global__ __launch_bounds__(256) void gather_kk_kernel(FlipArgs g) {
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int k = g.d_cnt[n];
+    double* A = g.Lws + (size_t)n * KMAX * KMAX;
+    const double* M = g.M + (long)n * g.strideM;
+    const int* idx = g.d_idx + (long)n * KMAX;
+    const int e = blockIdx.x * 256 + tid;
+    if (e >= 2 * KB2 * 2 * KB2) return;
+    const int i = e / (2 * KB2), j = e % (2 * KB2);
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < k && j < k) v = tab_get(M, g.ldj, idx[i], idx[j]);
+    A[i * KMAX + j] = v;
+}
+
+// dst[o+i][o+j] = (src[o.., o..])^-1 for the 128 x 128 block at offset o (in-LDS symmetric sweeps; the block is definite)
+__global__ __launch_bounds__(256) void invert128_kernel(FlipArgs g, const double* src_base, double* dst_base, int o) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int k = g.d_cnt[n];
+    constexpr int kk = KB2, ld = KB2 + 1;
+    double* colp = lds;                       // [128]
+    double* A = lds + KB2;
+    const double* src = src_base + (size_t)n * KMAX * KMAX;
+    double* dst = dst_base + (size_t)n * KMAX * KMAX;
+    if (k <= o) {                             // nothing real in this block (the frame holds the identity there)
+        for (int e = tid; e < kk * kk; e += 256) dst[(o + e / kk) * KMAX + o + e % kk] = (e / kk == e % kk) ? 1.0 : 0.0;
+        return;
+    }
+    for (int e = tid; e < kk * kk; e += 256) {
+        const int i = e / kk, j = e % kk;
+        A[i * ld + j] = src[(o + i) * KMAX + o + j];
+    }
+    __syncthreads();
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    for (int p = 0; p < kk; ++p) {
+        for (int i = tid; i < kk; i += 256) colp[i] = A[i * ld + p];
+        __syncthreads();
+        const double d = colp[p];
+        if (tid == 0 && !(d > 0.0)) s_bad = 1;
+        const double inv = 1.0 / d;
+        for (int e = tid; e < kk * kk; e += 256) {
+            const int i = e / kk, j = e % kk;
+            double v;
+            if (i == p && j == p) v = -inv;
+            else if (i == p) v = colp[j] * inv;
+            else if (j == p) v = colp[i] * inv;
+            else v = A[i * ld + j] - colp[i] * colp[j] * inv;
+            A[i * ld + j] = v;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < kk * kk; e += 256) {
+        const int i = e / kk, j = e % kk;
+        dst[(o + i) * KMAX + o + j] = -A[i * ld + j];
+    }
+    if (tid == 0 && s_bad) atomicOr(&g.status[n], 2);
+}
+
+// off-diagonal blocks from the scratch frame, zeros outside the k x k corner, padded K for the panel products
+__global__ __launch_bounds__(256) void finalize_g_kernel(FlipArgs g) {
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int k = g.d_cnt[n];
+    double* Gn = g.G + (size_t)n * KMAX * KMAX;
+    const double* A = g.Lws + (size_t)n * KMAX * KMAX;
+    const int e = blockIdx.x * 256 + tid;
+    if (e == 0) g.batch_k[n] = (k + 15) & ~15;
+    if (e >= KMAX * KMAX) return;
+    const int i = e / KMAX, j = e % KMAX;
+    double v = 0.0;
+    if (i < k && j < k) {
+        if (i >= KB2 && j < KB2) v = A[i * KMAX + j];                 // G_BA
+        else if (i < KB2 && j >= KB2) v = A[j * KMAX + i];            // G_AB = G_BA'
+        else v = Gn[e];
+    }
+    Gn[e] = v;
+}
+
 // ------------------------------------------------------------------ Ut[q][c] = M[idx[q], c]  (old panel, k-major), zero rows up to the padded K
 __global__ __launch_bounds__(256) void gather_panel_kernel(FlipArgs g) {
     const int n = blockIdx.y;
@@ -349,14 +435,43 @@ int pgl_k_flip_window_blocks(int B) {
 }
 
 // apply the pivot list currently in (d_idx, d_sign, d_cnt) to every neuron's tableau
-int pgl_k_flip_apply(const PglFlipState& s, int have_G, hipStream_t st) {
+int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, hipStream_t st) {
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, pgl_k_flip_window_blocks(s.B), s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
                s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status};
     const size_t lds_inv = ((size_t)KMAX + 128 * 129) * sizeof(double);
     static bool once = false;
     if (!once) { int rc = set_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv); if (rc) return rc; once = true; }
     const int Md = s.N * s.B + 2;
-    if (!have_G) {
+    if (!have_G && max_pivots > KB2) {
+        if (max_pivots > 2 * KB2) { pgl_set_error("flip_apply: %d pivots per call (max %d)", max_pivots, 2 * KB2); return PGL_ERR_ARG; }
+        static bool once2 = false;
+        const size_t lds128 = ((size_t)KB2 + KB2 * (KB2 + 1)) * sizeof(double);
+        if (!once2) { int rc = set_lds(reinterpret_cast<const void*>(invert128_kernel), lds128); if (rc) return rc; once2 = true; }
+        const long sq = (long)KMAX * KMAX;
+        double* Akk = s.Lws;
+        hipLaunchKernelGGL(gather_kk_kernel, dim3(2 * KB2 * 2 * KB2 / 256, s.nb), dim3(256), 0, st, g);
+        PGL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(invert128_kernel, dim3(s.nb), dim3(256), lds128, st, g, (const double*)Akk, s.G, 0);
+        PGL_CHECK_LAUNCH();
+        auto block_gemm = [&](const double* A, const double* Bm, double* C, double alpha, double beta) {
+            PglGemmArgs q{};
+            q.A = A; q.lda = KMAX; q.strideA = sq; q.B = Bm; q.ldb = KMAX; q.strideB = sq; q.C = C; q.ldc = KMAX; q.strideC = sq;
+            q.M = KB2; q.N = KB2; q.K = KB2; q.a_cols = KB2; q.b_cols = KB2; q.nbatch = s.nb; q.alpha = alpha; q.beta = beta; q.tri = 0;
+            return pgl_launch_gemm(PGL_GEMM_PLAIN, q, st);
+        };
+        double* G_AA = s.G;                 double* T = s.G + KB2;                    // T  (A x B) in G's upper-right block
+        double* Tt = s.G + (long)KB2 * KMAX; double* G_BB = s.G + (long)KB2 * KMAX + KB2;
+        const double* M_AB = Akk + KB2;     double* S = Akk + (long)KB2 * KMAX + KB2; double* G_BA = Akk + (long)KB2 * KMAX;
+        int rc = block_gemm(G_AA, M_AB, T, 1.0, 0.0);            if (rc) return rc;   // T  = G_A M_AB
+        rc = block_gemm(M_AB, G_AA, Tt, 1.0, 0.0);               if (rc) return rc;   // T' = M_BA G_A
+        rc = block_gemm(M_AB, T, S, -1.0, 1.0);                  if (rc) return rc;   // S  = M_BB - M_BA T
+        hipLaunchKernelGGL(invert128_kernel, dim3(s.nb), dim3(256), lds128, st, g, (const double*)Akk, s.G, KB2);   // G_BB = S^-1
+        PGL_CHECK_LAUNCH();
+        rc = block_gemm(G_BB, Tt, G_BA, -1.0, 0.0);              if (rc) return rc;   // G_BA = -S^-1 T'
+        rc = block_gemm(G_BA, Tt, G_AA, -1.0, 1.0);              if (rc) return rc;   // G_AA = G_A - G_BA' T'
+        hipLaunchKernelGGL(finalize_g_kernel, dim3((KMAX * KMAX + 255) / 256, s.nb), dim3(256), 0, st, g);
+        PGL_CHECK_LAUNCH();
+    } else if (!have_G) {
         hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);
         PGL_CHECK_LAUNCH();
     }

@@ -58,13 +58,26 @@ __device__ __forceinline__ void block_sync_lds() {
 }
 
 // one work item = one output tile of one batch (weighted mode: of one group of WZ weight columns)
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA = false>
+// CINIT (2-stage pipeline, alpha = +-1, beta = 1): the accumulators START from the C tile (loads issued together with the first K
+// tile, so their latency overlaps the pipeline fill) and the epilogue only stores.  The rank-k tableau / Cholesky updates are
+// short (K = 128..320) read-modify-write items whose serial epilogue loads cost as much as a third of the MFMA time.
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA = false, bool CINIT = false>
 __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, double* smem) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     const int ntm = (g.M + C::BM - 1) / C::BM;
     int tile, batch, tm, tn;
-    if (g.nbatch > 1) { tile = (int)(w / g.nbatch); batch = (int)(w % g.nbatch); }
-    else { tile = (int)w; batch = 0; }
+    if (g.nbatch > 1) {
+        if (WEIGHTED || (g.strideA == 0 && g.strideB == 0)) {
+            // shared operands (the Gram's X): the same tile of consecutive batches runs side by side and shares its panels in L2
+            tile = (int)(w / g.nbatch); batch = (int)(w % g.nbatch);
+        } else {
+            // per-batch operands (tableau / Cholesky panels): nothing is shared between batches, so each XCD walks one batch's tiles
+            // in order -- a row of tiles re-reads the same A strip and the B strips of one batch stay L2-resident
+            const int ntn_ = (g.N + C::BN - 1) / C::BN;
+            const long ntiles = g.tri ? (long)ntm * (ntm + 1) / 2 : (long)ntm * ntn_;
+            batch = (int)(w / ntiles); tile = (int)(w % ntiles);
+        }
+    } else { tile = (int)w; batch = 0; }
     if (g.tri) { tm = isqrt_tri(tile); tn = tile - tm * (tm + 1) / 2; if (g.tri == 2) { const int s_ = tm; tm = tn; tn = s_; } }
     else { tm = tile % ntm; tn = tile / ntm; }
     int Mv = g.M, Nv = g.N;
@@ -92,6 +105,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     // ---- loader geometry: a row of BM (BN) doubles is BM/2 (BN/2) 16-byte pieces
     double2 ra[C::A_LD], rb[C::B_LD];
     double rw = 0.0;
+    const double asign = CINIT ? g.alpha : 1.0;     // CINIT: alpha = +-1 is folded into the A operand on its way to LDS
     auto gload = [&](int kt) {
         const long krow = (long)kt * BK;
 #pragma unroll
@@ -117,7 +131,8 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
         for (int i = 0; i < C::A_LD; ++i) {
             const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-            *reinterpret_cast<double2*>(As + r * C::SA + c) = ra[i];
+            if constexpr (CINIT) *reinterpret_cast<double2*>(As + r * C::SA + c) = double2{ra[i].x * asign, ra[i].y * asign};
+            else *reinterpret_cast<double2*>(As + r * C::SA + c) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < C::B_LD; ++i) {
@@ -128,12 +143,34 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     };
 
     d4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-
     const int frow = lane >> 4, fcol = lane & 15;
+    const bool interior = CINIT && m0 + C::BM <= Mv && n0 + C::BN <= Nv;     // workgroup-uniform: no bounds checks inside the tile
+    if constexpr (CINIT) {
+        const double* __restrict__ cp = g.C + (long)batch * g.strideC + (long)(m0 + wm * 64 + frow) * g.ldc + (n0 + wn * 64 + fcol);
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j][r] = cp[(long)(i * 16 + 4 * r) * g.ldc + j * 16];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = m0 + wm * 64 + i * 16 + frow + 4 * r, col = n0 + wn * 64 + j * 16 + fcol;
+                        acc[i][j][r] = (row < Mv && col < Nv) ? cp[(long)(i * 16 + 4 * r) * g.ldc + j * 16] : 0.0;
+                    }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
     auto compute = [&](int buf, int kk) {
         const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
         const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
@@ -289,6 +326,28 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     constexpr bool WIDE = STAGES == 3;
     auto roff = [&](int i, int j) { return WIDE ? wmn * 32 + ((4 * i + j) >> 3) * 16 : wm * 64 + i * 16; };
     auto coff = [&](int i, int j) { return WIDE ? ((4 * i + j) & 7) * 16 : wn * 64 + j * 16; };
+    if constexpr (CINIT) {
+        double* __restrict__ cq = Cb + (long)(m0 + wm * 64 + frow) * g.ldc + (n0 + wn * 64 + fcol);
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cq[(long)(i * 16 + 4 * r) * g.ldc + j * 16] = acc[i][j][r];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = m0 + wm * 64 + i * 16 + frow + 4 * r, col = n0 + wn * 64 + j * 16 + fcol;
+                        if (row < Mv && col < Nv) cq[(long)(i * 16 + 4 * r) * g.ldc + j * 16] = acc[i][j][r];
+                    }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         double cv[4][4];
@@ -318,7 +377,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 
 // ---- plain launch: one workgroup per work item, XCD-aware order (block b runs on XCD b % 8: consecutive slots of one XCD
 // walk the batch index of the same tile, so co-resident workgroups share operand panels through that XCD's L2)
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool CINIT = false>
 __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -327,7 +386,7 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     const long chunk = (total + 7) / 8;
     long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
-    gemm_item<WM, WN, WZ, WEIGHTED, STAGES>(g, w, smem);
+    gemm_item<WM, WN, WZ, WEIGHTED, STAGES, false, CINIT>(g, w, smem);
 }
 
 // ---- persistent launch (long launches: the hardware dispatcher's round-robin drifts after a few hundred rounds and the
@@ -365,11 +424,14 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64_persistent(Pgl
     }
 }
 
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2, bool CINIT = false>
 int launch(const PglGemmArgs& a, hipStream_t st) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
+    if constexpr (!WEIGHTED && STAGES == 2 && !CINIT) {
+        if (a.beta == 1.0 && (a.alpha == 1.0 || a.alpha == -1.0)) return launch<WM, WN, WZ, WEIGHTED, STAGES, true>(a, st);
+    }
     static bool attr_set = false;
-    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED, STAGES>;
+    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED, STAGES, CINIT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", C::LDS_BYTES, hipGetErrorString(e)); return PGL_ERR_HIP; }

@@ -364,7 +364,7 @@ class GibbsEngine(object):
                     blocks = np.nonzero(a_host[s + i])[0]
                     rows = (blocks[:, None] * B + np.arange(B)[None, :]).ravel()
                     lists.append(np.concatenate(([D], rows)).astype(np.int32))
-            ck = 128                                     # pivots per initial chunk: inverted in LDS by pgl_flip_apply
+            ck = 256                                     # pivots per initial chunk (pgl_flip_apply_chunk: 2 x 2 blocks of 128)
             nchunk = max((len(l) + ck - 1) // ck for l in lists)
             for c in range(nchunk):
                 idx = np.zeros((self.nb, kmax), dtype=np.int32)
@@ -376,11 +376,17 @@ class GibbsEngine(object):
                 self.d_idx.copy_(torch.from_numpy(idx))
                 self.d_cnt.copy_(torch.from_numpy(cnt))
                 self.d_sign.fill_(1.0)
-                call("pgl_flip_apply", ctypes.byref(fs), st)
+                h2 = self._tic("flips.init")
+                call("pgl_flip_apply_chunk", ctypes.byref(fs), int(cnt.max()), st)
+                self._toc(h2)
             nwin = (N + self.R - 1) // self.R
             for w in range(nwin):
+                h2 = self._tic("flips.decide")
                 call("pgl_flip_decide", ctypes.byref(fs), w, st)
+                self._toc(h2)
+                h2 = self._tic("flips.apply")
                 call("pgl_flip_apply_window", ctypes.byref(fs), st)
+                self._toc(h2)
         self._toc(hf)
         hc_ = self._tic("weights")
         # ---- weights (regression.py:323-340)

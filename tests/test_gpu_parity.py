@@ -215,6 +215,34 @@ def test_sweep_vs_oracle(torch_dev, N, B, T, rho, batch):
         assert (a1 != a).sum() > 0
 
 
+def test_sweep_vs_oracle_large_initial_active_set(torch_dev):
+    """initial active sets of ~380 rows: the tableau is initialised in chunks of 256 pivots (pivot-block inverse by 2 x 2 blocks
+    of 128, rank-256 updates) plus a remainder chunk; neurons with fewer than 129 / 257 rows share the same launches"""
+    from pyglm_amd.engine import make_draws
+    N, B, T = 110, 4, 2500
+    basis, X, Y, rng = _random_problem(N, B, T, seed=5)
+    kw = dict(rho=0.6, S_w=4.0, mu_w=0.0, mu_b=-1.5, S_b=2.0)
+    a = rng.random((N, N)) < 0.85
+    a[3] = rng.random(N) < 0.2             # 23 blocks: a single sub-128 chunk
+    a[7] = rng.random(N) < 0.45            # ~200 rows: one chunk with a partial second block
+    a[11] = True                           # all 441 rows: 256 + 185
+    W = rng.standard_normal((N, N, B)) * 0.3 * a[:, :, None]
+    b = rng.standard_normal(N) - 1.5
+    eng = _engine(N, B, batch=64)
+    eng.add_data(Y, X=X)
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    rho_a, Jw, hw, Jb, hb, c0 = _hyp(regs)
+    perm, u, z = make_draws(77, 1, range(N), N, N * B)
+    a1, W1, b1, _ = eng.sweep(a, W, b, rho_a, Jw, hw, Jb, hb, c0, perm, u, z, seed=77, sweep=1)
+    omegas = eng.datasets[0].OK[:T, :N].cpu().numpy()
+    outs = _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z)
+    for n, (ao, Wo, bo, trace) in enumerate(outs):
+        np.testing.assert_array_equal(a1[n], ao, err_msg="adjacency row %d" % n)
+        np.testing.assert_allclose(W1[n], Wo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(b1[n], bo[0], rtol=1e-7, atol=1e-9)
+    assert (a1 != a).sum() > 100
+
+
 def test_sharded_equals_unsharded(torch_dev):
     """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit"""
     from pyglm_amd.engine import make_draws
