@@ -79,9 +79,11 @@ int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long
                     double alpha, double beta, void* hip_stream);
 /* J_post = J_lkhd + J_prior, h_post = h_lkhd + h_prior in the (D+2)-square layout [J, bias row D, potential row D+1].
  * Replaces _prior_sufficient_statistics + the additions at pyglm/regression.py:210-223, 253-260, 270-271.
- * border: 2*nloc_b rows (omega sums then kappa sums) x ldb; Jw [nb][N][B][B], hw [nb][N][B], Jb [nb], hb [nb]. */
+ * border: 2*nloc_b rows (omega sums then kappa sums) x ldb; Jb [nb], hb [nb]; the block-diagonal prior either dense, Jw [nb][N][B][B] and
+ * hw [nb][N][B] with label = NULL, or as tables of the K distinct blocks, Jw [K][B][B] and hw [K][B], with label [nb][N] naming the
+ * block of (postsynaptic n, presynaptic m) -- a network prior (pyglm/networks.py) pushes a handful of distinct blocks. */
 int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* border_omega, const double* border_kappa, long ldb, const double* Jw,
-                           const double* hw, const double* Jb, const double* hb, int nb, int N, int B, void* hip_stream);
+                           const double* hw, const int* label, const double* Jb, const double* hb, int nb, int N, int B, void* hip_stream);
 
 /* ---- collapsed adjacency resampling (pyglm/regression.py:282-320 + 343-378) ------------------------------------ */
 typedef struct {

@@ -37,7 +37,7 @@ SIGNATURES = {
     "pgl_scaled_gram": [c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_i, c_p],
     "pgl_weighted_gram": [c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
-    "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "pgl_flip_kmax": [],
     "pgl_flip_window_blocks": [c_i],
     "pgl_flip_apply": [ctypes.POINTER(FlipState), c_p],

@@ -23,8 +23,8 @@ int pgl_k_gaussian_stats(double*, long, const double*, const double*, long, cons
 int pgl_k_scaled_gram(const double*, long, const double*, double*, long, long, int, int, hipStream_t);
 int pgl_k_basis_conv(const double*, long, const double*, double*, long, double*, long, int, int, int, int, int, hipStream_t);
 int pgl_k_transpose(const double*, long, double*, long, int, int, hipStream_t);
-int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const double*, const double*, int,
-                        int, int, hipStream_t);
+int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const int*, const double*,
+                        const double*, int, int, int, hipStream_t);
 struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
@@ -130,10 +130,10 @@ int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long
 }
 
 int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* border_omega, const double* border_kappa, long ldb, const double* Jw,
-                           const double* hw, const double* Jb, const double* hb, int nb, int N, int B, void* st) {
+                           const double* hw, const int* label, const double* Jb, const double* hb, int nb, int N, int B, void* st) {
     PGL_CHECK_ARG(J && border_omega && border_kappa && Jw && hw && Jb && hb && nb > 0 && N > 0 && B > 0);
     PGL_CHECK_ARG(ldj >= (long)N * B + 2 && ldb >= (long)N * B + 1);
-    return pgl_k_assemble_post(J, ldj, strideJ, border_omega, border_kappa, ldb, Jw, hw, Jb, hb, nb, N, B, ST(st));
+    return pgl_k_assemble_post(J, ldj, strideJ, border_omega, border_kappa, ldb, Jw, hw, label, Jb, hb, nb, N, B, ST(st));
 }
 
 static PglFlipState to_state(const pgl_flip_t* s) {

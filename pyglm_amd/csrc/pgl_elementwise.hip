@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 struct PostArgs {
     double* J; long ldj; long strideJ;
     const double* bo; const double* bk; long ldb;   // [nb][ldb] each: sum_t omega X~ and sum_t kappa X~ (col D = plain sums)
-    const double* Jw;                 // [nloc][N][B][B]
-    const double* hw;                 // [nloc][N][B]
+    const double* Jw;                 // [nloc][N][B][B], or (label != null) a table [K][B][B] of distinct blocks
+    const double* hw;                 // [nloc][N][B],    or a table [K][B]
+    const int* label;                 // [nloc][N] index of block (n, m) in the tables, or null
     const double* Jb;                 // [nloc]
     const double* hb;                 // [nloc]
     int nloc, N, B;
@@ -169,9 +170,10 @@ __global__ __launch_bounds__(256) void assemble_post_kernel(PostArgs g) {
         const double hk = g.bk[(long)n * g.ldb + c];
         if (c < D) {
             J[(long)D * g.ldj + c] = xs;
-            J[(long)(D + 1) * g.ldj + c] = hk + g.hw[(long)n * D + c];
             const int m = c / g.B, bi = c % g.B;
-            const double* jw = g.Jw + ((long)n * g.N + m) * g.B * g.B;
+            const long blk = g.label ? (long)g.label[(long)n * g.N + m] : (long)n * g.N + m;
+            J[(long)(D + 1) * g.ldj + c] = hk + g.hw[blk * g.B + bi];
+            const double* jw = g.Jw + blk * g.B * g.B;
             // lower-triangular part of the diagonal block (row r = m*B+bi, columns m*B .. r)
             for (int bj = 0; bj <= bi; ++bj) J[(long)c * g.ldj + m * g.B + bj] += jw[bi * g.B + bj];
         } else {
@@ -271,8 +273,8 @@ int pgl_k_transpose(const double* src, long lds_, double* dst, long ldd, int row
 }
 
 int pgl_k_assemble_post(double* J, long ldj, long strideJ, const double* bo, const double* bk, long ldb, const double* Jw, const double* hw,
-                        const double* Jb, const double* hb, int nloc, int N, int B, hipStream_t st) {
-    PostArgs a{J, ldj, strideJ, bo, bk, ldb, Jw, hw, Jb, hb, nloc, N, B};
+                        const int* label, const double* Jb, const double* hb, int nloc, int N, int B, hipStream_t st) {
+    PostArgs a{J, ldj, strideJ, bo, bk, ldb, Jw, hw, label, Jb, hb, nloc, N, B};
     const int D = N * B;
     hipLaunchKernelGGL(assemble_post_kernel, dim3((D + 1 + 255) / 256, nloc), dim3(256), 0, st, a);
     PGL_CHECK_LAUNCH();

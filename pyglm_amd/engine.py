@@ -59,6 +59,21 @@ def prior_terms(S_w, mu_w, S_b, mu_b):
     return Jw, hw, Jb, hb, c0
 
 
+class BlockPrior(object):
+    """block-diagonal weight prior of a shard in table form: the K distinct (J_w, h_w, c0) blocks and, per (local neuron, presynaptic
+    neuron), the index of its block.  A network prior pushes two or three distinct blocks for N^2 pairs; the tables travel to the
+    GPU instead of the expanded (nloc, N, B, B) array.  Accepted by GibbsEngine.sweep in place of the dense Jw (hw and c0 = None)."""
+
+    def __init__(self, Jw_u, hw_u, c0_u, label):
+        self.Jw_u = np.ascontiguousarray(Jw_u, dtype=np.float64)
+        self.hw_u = np.ascontiguousarray(hw_u, dtype=np.float64)
+        self.c0_u = np.ascontiguousarray(c0_u, dtype=np.float64)
+        self.label = np.ascontiguousarray(label, dtype=np.int32)
+
+    def dense(self):
+        return self.Jw_u[self.label], self.hw_u[self.label], self.c0_u[self.label]
+
+
 class _Dataset(object):
     pass
 
@@ -274,10 +289,12 @@ class GibbsEngine(object):
         return ds.Psi[:, :self.nloc].cpu().numpy()
 
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
-    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None):
+    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None):
         """regression.py:265-280 for every local neuron.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in
         natural form (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
-        omega_override: list of (T, nloc) arrays replacing the PG draws (test hook: the reference fixtures inject omega)."""
+        omega_override: list of (T, nloc) arrays replacing the PG draws (test hook: the reference fixtures inject omega).
+        host_overlap: optional callable run on the host once the first batch's Gram has been queued (seconds of GPU work during
+        which the host would only wait), e.g. to draw the next sweep's permutations."""
         nloc, N, B, D, ldn, Dp, ldj = self.nloc, self.N, self.B, self.D, self.ldn, self.Dp, self.ldj
         st = self._st()
         a = np.asarray(a).astype(bool).copy()
@@ -297,17 +314,23 @@ class GibbsEngine(object):
         a_i32 = torch.from_numpy(a.astype(np.int32)).to(self.dev)
         self.a_dev.copy_(a_i32)
         self.status.zero_()
+        label = None
+        if isinstance(Jw, BlockPrior):
+            label, c0, hw, Jw = Jw.label, Jw.c0_u[Jw.label], Jw.hw_u, Jw.Jw_u
         d = dict(rho=rho, Jw=Jw, hw=hw, Jb=Jb, hb=hb, c0=c0, perm=perm, u=u, z=z)
         dev = {}
         for k, v in d.items():
             arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
             dev[k] = torch.from_numpy(arr).to(self.dev)
+        dev["label"] = None if label is None else torch.from_numpy(label).to(self.dev)
         skip = torch.from_numpy(det.astype(np.int32)).to(self.dev)
         # One batch after the other on the current stream.  (Running batch k's flips / weight draw on a second stream behind batch
         # k+1's Gram was tried: bit-identical but no faster -- both stages compete for CU time)
         for s0 in range(0, nloc, self.nb):
             nbb = min(self.nb, nloc - s0)
             self._gram(s0, nbb, 0)
+            if host_overlap is not None and s0 == 0:
+                host_overlap()
             self._post(s0, nbb, 0, a, det, dev, skip)
         torch.cuda.synchronize(self.dev)
         status = self.status.cpu().numpy()
@@ -346,8 +369,12 @@ class GibbsEngine(object):
         off8 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 8 * int(elems))
         off4 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
         # ---- posterior assembly (regression.py:210-223, 253-260, 270-271)
+        if dev["label"] is None:
+            jw_p, hw_p, lab_p = off8(dev["Jw"], s * N * B * B), off8(dev["hw"], s * N * B), None
+        else:
+            jw_p, hw_p, lab_p = ptr(dev["Jw"]), ptr(dev["hw"]), off4(dev["label"], s * N)
         call("pgl_assemble_posterior", ptr(self.Jbuf), ldj, strideJ, off8(self.border, s * Dp), off8(self.border, (ldn + s) * Dp), Dp,
-             off8(dev["Jw"], s * N * B * B), off8(dev["hw"], s * N * B), off8(dev["Jb"], s), off8(dev["hb"], s), nbb, N, B, st)
+             jw_p, hw_p, lab_p, off8(dev["Jb"], s), off8(dev["hb"], s), nbb, N, B, st)
         # ---- collapsed flips (regression.py:282-320)
         hf = self._tic("flips")
         if not det[s:s + nbb].all():

@@ -36,6 +36,7 @@ def shard_bounds(N, world, rank):
 
 class NonlinearAutoregressiveModel(object):
     """(models.py:8-201) y_n[t] ~ p(f(w_n . x[t])), x = basis-filtered history of all neurons."""
+    DRAW_AHEAD_MIN_SIZE = 1 << 16      # N*N*B above which the next sweep's host draws are made while the GPU is busy
 
     def __init__(self, N, regressions, basis=None, B=10, device=None, engine_factory=None, seed=None, engine_kwargs=None):
         self.N = N
@@ -220,11 +221,24 @@ class NonlinearAutoregressiveModel(object):
             mu_b = np.array([r.mu_b[0] for r in regs])
             Jw, hw, Jb, hb, c0 = prior_terms(S_w, mu_w, S_b, mu_b)
             self._hyper_cache = (versions, (rho, Jw, hw, Jb, hb, c0))
-        perm, u, z = make_draws(self.seed, self.sweeps_done, range(self.n0, self.n1), self.N, self.N * self.B)
+        # the non-PG random inputs depend on (seed, sweep, neuron) only: those of the NEXT sweep are drawn while the GPU works on
+        # this one (engine.sweep's host_overlap hook) and picked up here
+        key = (self.seed, self.sweeps_done, self.n0, self.n1)
+        pre = getattr(self, "_draws_ahead", None)
+        if pre is not None and pre[0] == key:
+            perm, u, z = pre[1]
+        else:
+            perm, u, z = make_draws(self.seed, self.sweeps_done, range(self.n0, self.n1), self.N, self.N * self.B)
+        self._draws_ahead = None
+
+        def draw_ahead():
+            nxt = (self.seed, self.sweeps_done + 1, self.n0, self.n1)
+            self._draws_ahead = (nxt, make_draws(self.seed, self.sweeps_done + 1, range(self.n0, self.n1), self.N, self.N * self.B))
         gaussian = self.engine_obs() == "gaussian"
         if gaussian:
             self.engine.set_noise([r.eta for r in regs])
-        a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done)
+        kw = dict(host_overlap=draw_ahead) if self.N * self.N * self.B >= self.DRAW_AHEAD_MIN_SIZE else {}
+        a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done, **kw)
         if gaussian:
             # noise variances (regression.py:433-445): residual sums of squares under the NEW weights from the device, gamma draws
             # keyed by the global neuron index
@@ -325,13 +339,12 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
         idx = label
         Jw_u, hw_u, _, _, c0_u = prior_terms(u[:, :B * B].reshape(1, -1, B, B), u[:, B * B:].reshape(1, -1, B), np.ones(1), np.zeros(1))
         nl = n1 - n0
-        Jw = Jw_u[0][idx].reshape(nl, N, B, B)
-        hw = hw_u[0][idx].reshape(nl, N, B)
-        c0 = c0_u[0][idx].reshape(nl, N)
+        from .engine import BlockPrior
+        prior = BlockPrior(Jw_u[0], hw_u[0], c0_u[0], idx.reshape(nl, N))      # tables + labels: never expanded to (nl, N, B, B)
         S_b = np.array([r.S_b[0, 0] for r in regs])
         mu_b = np.array([r.mu_b[0] for r in regs])
         Jb = 1.0 / S_b
-        self._hyper_cache = (tuple(r._hyp_version for r in regs), (np.array(rho[n0:n1], dtype=float), Jw, hw, Jb, Jb * mu_b, c0))
+        self._hyper_cache = (tuple(r._hyp_version for r in regs), (np.array(rho[n0:n1], dtype=float), prior, None, Jb, Jb * mu_b, None))
 
 
 GLM = NonlinearAutoregressiveModel

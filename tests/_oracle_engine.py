@@ -51,8 +51,12 @@ class OracleEngine(object):
         X = self.datasets[i][0]
         return np.column_stack([self._reg(a, W, b, k).activation(X) for k in range(self.nloc)])
 
-    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None):
+    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None):
         a_new, W_new, b_new, ll = [], [], [], self.log_likelihood(a, W, b)
+        if hasattr(Jw, "dense"):          # pyglm_amd.engine.BlockPrior (tables + labels)
+            Jw, hw, c0 = Jw.dense()
+        if host_overlap is not None:
+            host_overlap()
         for i in range(self.nloc):
             S_w = np.linalg.inv(Jw[i])
             mu_w = np.einsum("mij,mj->mi", S_w, hw[i])

@@ -130,7 +130,9 @@ def test_pushed_hyper_cache_equals_dense_terms():
     N, B = 7, 3
     m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
     m.resample_network()
-    versions, (rho, Jw, hw, Jb, hb, c0) = m._hyper_cache
+    versions, (rho, prior, _, Jb, hb, _) = m._hyper_cache
+    assert prior.Jw_u.shape[0] <= 3 and prior.label.shape == (N, N)      # a handful of distinct blocks, never expanded
+    Jw, hw, c0 = prior.dense()
     regs = m.regressions
     want = prior_terms(np.array([r.S_w for r in regs]), np.array([r.mu_w for r in regs]), np.array([r.S_b[0, 0] for r in regs]),
                        np.array([r.mu_b[0] for r in regs]))
@@ -164,3 +166,24 @@ def test_api_error_behaviour_matches_reference():
     assert m.generate(T=0).shape == (0, 3)
     with pytest.raises(AssertionError):
         m.generate(T=2.5)
+
+
+def test_draws_made_ahead_equal_draws_made_on_time():
+    """the next sweep's permutations / uniforms / normals may be drawn while the GPU is busy (engine.sweep's host_overlap hook):
+    the chain must not depend on when they were drawn"""
+    from tests._oracle_engine import OracleEngine
+    from pyglm_amd.models import SparseBernoulliGLM
+    out = []
+    for min_size in (1 << 30, 0):
+        np.random.seed(4)
+        N, B, T = 4, 2, 300
+        Y = (np.random.rand(T, N) < 0.2).astype(float)
+        m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=21, engine_factory=OracleEngine)
+        m.DRAW_AHEAD_MIN_SIZE = min_size
+        m.add_data(Y)
+        for _ in range(3):
+            m.resample_model()
+        assert (m._draws_ahead is not None) == (min_size == 0)
+        out.append((m.adjacency.copy(), m.weights.copy(), m.biases.copy()))
+    for x, y in zip(*out):
+        np.testing.assert_array_equal(x, y)
