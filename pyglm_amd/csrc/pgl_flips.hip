@@ -358,53 +358,116 @@ __global__ __launch_bounds__(256) void finalize_g_kernel(FlipArgs g) {
 }
 
 // ------------------------------------------------------------------ Ut[q][c] = M[idx[q], c]  (old panel, k-major), zero rows up to the padded K
+// The tableau stores its lower triangle, so row idx[q] of the symmetric matrix is a stored row up to the diagonal and a stored
+// COLUMN beyond it.  One workgroup moves a 64 (columns c) x 64 (pivots q) tile.  Where the whole tile lies left of the diagonal the
+// stored rows are copied lane-per-column; elsewhere lanes run along q -- row c read at the columns idx[q..q+63], which sit in a few
+// contiguous runs -- and the tile is turned in LDS so that the writes to Ut are again lane-per-column.
+constexpr int GT = 64;
 __global__ __launch_bounds__(256) void gather_panel_kernel(FlipArgs g) {
-    const int n = blockIdx.y;
+    const int n = blockIdx.z;
     const int k = g.d_cnt[n];
     if (k <= 0) return;
     const int kp = (k + 15) & ~15;
+    const int q0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+    if (q0 >= kp) return;
     const int Md = g.N * g.B + 2;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= g.ldu) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* M = g.M + (long)n * g.strideM;
     const int* idx = g.d_idx + (long)n * KMAX;
     double* Ut = g.Ut + (long)n * KMAX * g.ldu;
-    for (int q = 0; q < kp; ++q) {
-        double v = 0.0;
-        if (q < k && c < Md) v = tab_get(M, g.ldj, idx[q], c);
-        Ut[(long)q * g.ldu + c] = v;
+    __shared__ int s_idx[GT];
+    __shared__ int s_min;
+    __shared__ double tile[GT][GT + 1];
+    if (threadIdx.x < GT) s_idx[threadIdx.x] = (q0 + threadIdx.x < k) ? idx[q0 + threadIdx.x] : -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int mn = 0x7fffffff;
+        for (int i = 0; i < GT; ++i) if (s_idx[i] >= 0 && s_idx[i] < mn) mn = s_idx[i];
+        s_min = mn;
     }
+    __syncthreads();
+    const int c = c0 + lane;
+    if (c0 + GT - 1 <= s_min) {                       // stored rows only
+        if (c >= g.ldu) return;
+        for (int qi = wave; qi < GT && q0 + qi < kp; qi += 4) {
+            const int gq = s_idx[qi];
+            Ut[(long)(q0 + qi) * g.ldu + c] = (gq >= 0 && c < Md) ? M[(long)gq * g.ldj + c] : 0.0;
+        }
+        return;
+    }
+    const int gq = s_idx[lane];
+    for (int ci = wave; ci < GT; ci += 4) {
+        const int cc = c0 + ci;
+        tile[ci][lane] = (gq >= 0 && cc < Md) ? tab_get(M, g.ldj, gq, cc) : 0.0;
+    }
+    __syncthreads();
+    if (c >= g.ldu) return;
+    for (int qi = wave; qi < GT && q0 + qi < kp; qi += 4) Ut[(long)(q0 + qi) * g.ldu + c] = tile[lane][qi];
 }
 
 // ------------------------------------------------------------------ pivot rows/columns after the rank-k update
+// M_sym[idx[q], c] = sg[q] Wt[q][c] for non-pivot c;  = -sg[q] G[q][r] sg[r] where c = idx[r] (written once, from the side gq >= c).
+// Same 64 x 64 tiling and the same two access patterns as the gather, in the opposite direction.
 __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
-    const int n = blockIdx.y;
+    const int n = blockIdx.z;
     const int k = g.d_cnt[n];
-    if (k <= 0) return;
-    __shared__ int s_idx[KMAX];
-    __shared__ double s_sg[KMAX];
-    __shared__ short s_piv[256];   // position in idx of column c, or -1
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int q0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+    if (k <= 0 || q0 >= k) return;
     const int Md = g.N * g.B + 2;
-    for (int q = threadIdx.x; q < k; q += 256) { s_idx[q] = g.d_idx[(long)n * KMAX + q]; s_sg[q] = g.d_sign[(long)n * KMAX + q]; }
-    s_piv[threadIdx.x] = -1;
-    __syncthreads();
-    for (int q = threadIdx.x; q < k; q += 256) {
-        const int cc = s_idx[q] - blockIdx.x * 256;
-        if (cc >= 0 && cc < 256) s_piv[cc] = (short)q;
-    }
-    __syncthreads();
-    if (c >= Md) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* M = g.M + (long)n * g.strideM;
+    const int* idx = g.d_idx + (long)n * KMAX;
+    const double* sgn = g.d_sign + (long)n * KMAX;
     const double* Wt = g.Wt + (long)n * KMAX * g.ldu;
     const double* Gn = g.G + (long)n * KMAX * KMAX;
-    const int r = s_piv[threadIdx.x];
-    for (int q = 0; q < k; ++q) {
-        const int gq = s_idx[q];
+    __shared__ int s_idx[GT];
+    __shared__ double s_sg[GT];
+    __shared__ int s_piv[GT];       // position in the pivot list of column c0 + i, or -1
+    __shared__ int s_min;
+    __shared__ double tile[GT][GT + 1];
+    if (threadIdx.x < GT) {
+        const bool ok = q0 + threadIdx.x < k;
+        s_idx[threadIdx.x] = ok ? idx[q0 + threadIdx.x] : -1;
+        s_sg[threadIdx.x] = ok ? sgn[q0 + threadIdx.x] : 0.0;
+        s_piv[threadIdx.x] = -1;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < k; q += 256) {
+        const int cc = idx[q] - c0;
+        if (cc >= 0 && cc < GT) s_piv[cc] = q;
+    }
+    if (threadIdx.x == 0) {
+        int mn = 0x7fffffff;
+        for (int i = 0; i < GT; ++i) if (s_idx[i] >= 0 && s_idx[i] < mn) mn = s_idx[i];
+        s_min = mn;
+    }
+    __syncthreads();
+    const int c = c0 + lane;
+    if (c0 + GT - 1 <= s_min) {                       // every pivot row of the tile is a stored row here
+        if (c >= Md) return;
+        const int r = s_piv[lane];
+        const double sr = r >= 0 ? sgn[r] : 0.0;
+        for (int qi = wave; qi < GT; qi += 4) {
+            const int gq = s_idx[qi];
+            if (gq < 0) break;
+            const double v = r < 0 ? s_sg[qi] * Wt[(long)(q0 + qi) * g.ldu + c] : -s_sg[qi] * Gn[(q0 + qi) * KMAX + r] * sr;
+            M[(long)gq * g.ldj + c] = v;
+        }
+        return;
+    }
+    for (int qi = wave; qi < GT; qi += 4)
+        tile[qi][lane] = (s_idx[qi] >= 0 && c < Md) ? s_sg[qi] * Wt[(long)(q0 + qi) * g.ldu + c] : 0.0;
+    __syncthreads();
+    const int gq = s_idx[lane];
+    if (gq < 0) return;
+    for (int ci = wave; ci < GT; ci += 4) {
+        const int cc = c0 + ci;
+        if (cc >= Md) break;
+        const int r = s_piv[ci];
         double v;
-        if (r < 0) v = s_sg[q] * Wt[(long)q * g.ldu + c];
-        else { if (gq < c) continue; v = -s_sg[q] * Gn[q * KMAX + r] * s_sg[r]; }
-        if (gq >= c) M[(long)gq * g.ldj + c] = v; else M[(long)c * g.ldj + gq] = v;
+        if (r < 0) v = tile[lane][ci];
+        else { if (gq < cc) continue; v = -s_sg[lane] * Gn[(q0 + lane) * KMAX + r] * sgn[r]; }
+        if (gq >= cc) M[(long)gq * g.ldj + cc] = v; else M[(long)cc * g.ldj + gq] = v;
     }
 }
 
@@ -475,7 +538,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, hipStrea
         hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);
         PGL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu + 255) / 256), s.nb), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu + GT - 1) / GT), KMAX / GT, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
     // Wt = G Ut   (K x ldu), then  M -= Wt' Ut  on lower-triangular tiles
     PglGemmArgs w{};
@@ -494,7 +557,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, hipStrea
     t.alpha = -1.0; t.beta = 1.0; t.tri = 1; t.batch_k = s.batch_k; t.batch_dim = nullptr; t.dim_off = 0; t.W = nullptr; t.ldw = 0;
     rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(fixup_kernel, dim3((Md + 255) / 256, s.nb), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(fixup_kernel, dim3((Md + GT - 1) / GT, KMAX / GT, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
