@@ -17,6 +17,7 @@
 //     contraction and the rank-k updates) and STAGES = 3, the Gram pipeline (global_load_lds DMA staging, barrier in the
 //     middle of a K tile, 32 x 128 wave tiles, every LDS read and DMA piece issued in the shadow of an MFMA, one cluster of
 //     omega multiplies per pair of k-steps).  DESIGN.md section 3.1 has the measurements behind each of these choices.
+//     gram_fine_item is the same Gram for launches with few neurons: 4-wave workgroups, one neuron each, two per CU.
 //   * XCD-aware order: work item w = xcd*chunk + slot with the batch (neuron pair) fastest, so the workgroups resident on
 //     one XCD share the same X panels through that XCD's L2; the Gram is launched persistently (one workgroup per CU
 //     pulling XCD-local items) because the dispatcher's round-robin drifts over long launches.
@@ -216,42 +217,56 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         // columns are clamped to a readable one: they only feed outputs that are never stored.
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-        // one tile = five DMA wave-instructions per wave: pieces 0..3 = (A row, B row) x 2, piece 4 = this wave's 8 weight dwords
-        auto dma_piece = [&](int kt, int stage, int p) {
-            static_assert(!DMA || (C::BM == 128 && C::BN == 128 && C::THREADS == 512), "DMA staging is written for the Gram tile");
-            const long krow = (long)kt * BK;
-            double* As = smem + stage * C::STAGE;
-            double* Bs = As + C::A_ELEMS;
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-            if (p < 4) {
-                const int r = wv + 8 * (p >> 1);
-                if ((p & 1) == 0) {
-                    int ca = m0 + lane * 2;
-                    ca = ca < g.a_cols ? ca : g.a_cols - 2;
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ab + (krow + r) * g.lda + ca), (lds_ptr_t)(As + r * C::SA), 16, 0, 0);
-                } else {
-                    int cb = n0 + lane * 2;
-                    cb = cb < g.b_cols ? cb : g.b_cols - 2;
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bb + (krow + r) * g.ldb + cb), (lds_ptr_t)(Bs + r * C::SB), 16, 0, 0);
-                }
-            } else if (WEIGHTED) {
-                // 16 x WZ doubles = 64 dwords, 8 per wave (lanes 0-7): every wave issues the same 5 DMA instructions per tile
-                if (lane < 8) {
-                    const int dw = wv * 8 + lane, dbl = dw >> 1, r = dbl / WZ, z = dbl % WZ;
-                    int zc = batch * WZ + z;
-                    zc = zc < g.nz_total ? zc : g.nz_total - 1;
-                    const float* src = reinterpret_cast<const float*>(g.W + (krow + r) * g.ldw + zc) + (dw & 1);
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(reinterpret_cast<float*>(Bs + C::B_ELEMS) + wv * 8), 4, 0, 0);
-                }
-            }
-        };
-        auto dma = [&](int kt, int stage) {
+        // one tile = five DMA wave-instructions per wave: pieces 0..3 = (A row, B row) x 2, piece 4 = this wave's 8 weight dwords.
+        // Every piece keeps a per-lane global cursor that is advanced by one K tile after each request, and a wave-uniform LDS
+        // offset inside a stage: a request is {m0 = stage base + offset; global_load_lds; 64-bit add}.  (Scalar bases + 32-bit lane
+        // offsets instead of cursors measured 0.5 % slower: the compiler rebuilds a 64-bit vector address per request.)  (Recomputing
+        // (krow + r) * ld per piece cost a dozen dependent scalar instructions and a branch in front of every request -- longer than
+        // the MFMA shadow it sat in, and both waves of a SIMD reach the same slot together: the MFMA pipe idled ~9 %.)  Past the last
+        // tile the cursors stop and the last tile is simply requested again into a stage nobody reads any more.
+        static_assert(C::BM == 128 && C::BN == 128 && C::THREADS == 512, "DMA staging is written for the Gram tile");
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const char* gp[5];
+        long gstep[5];
+        int loff[5];
+        {
+            int ca = m0 + lane * 2, cb = n0 + lane * 2;
+            ca = ca < g.a_cols ? ca : g.a_cols - 2;      // out-of-range columns are clamped to a readable one: they only feed
+            cb = cb < g.b_cols ? cb : g.b_cols - 2;      // outputs that are never stored
 #pragma unroll
-            for (int p = 0; p < 5; ++p) dma_piece(kt, stage, p);
+            for (int p = 0; p < 4; ++p) {
+                const int r = wv + 8 * (p >> 1);
+                if ((p & 1) == 0) { gp[p] = reinterpret_cast<const char*>(Ab + (long)r * g.lda + ca); gstep[p] = (long)BK * g.lda * 8; loff[p] = r * C::SA * 8; }
+                else { gp[p] = reinterpret_cast<const char*>(Bb + (long)r * g.ldb + cb); gstep[p] = (long)BK * g.ldb * 8; loff[p] = (C::A_ELEMS + r * C::SB) * 8; }
+            }
+            // 16 x WZ doubles = 64 dwords, 8 per wave (lanes 0-7)
+            const int dw = wv * 8 + (lane & 7), dbl = dw >> 1, r = dbl / WZ, zq = dbl % WZ;
+            int zc = batch * WZ + zq;
+            zc = zc < g.nz_total ? zc : g.nz_total - 1;
+            gp[4] = reinterpret_cast<const char*>(g.W + (long)r * g.ldw + zc) + 4 * (dw & 1);
+            gstep[4] = (long)BK * g.ldw * 8;
+            loff[4] = (C::A_ELEMS + C::B_ELEMS) * 8 + wv * 32;
+        }
+        long gadv[5];
+        auto advance = [&](bool adv) {       // cursor step of the requests that follow (0 once the last tile has been requested)
+#pragma unroll
+            for (int p = 0; p < 5; ++p) gadv[p] = adv ? gstep[p] : 0;
         };
-        dma(0, 0);
+        auto dma_piece = [&](int stage, int p) {
+            char* dst = reinterpret_cast<char*>(smem) + (size_t)stage * C::STAGE * 8 + loff[p];
+            if (p < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[p], (lds_ptr_t)dst, 16, 0, 0);
+            else if (lane < 8) __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[4], (lds_ptr_t)dst, 4, 0, 0);
+            gp[p] += gadv[p];
+        };
+        auto dma = [&](int stage) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) dma_piece(stage, p);
+        };
+        advance(1 < nkt);
+        dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (nkt > 1) dma(1, 1);
+        advance(2 < nkt);
+        dma(1);                      // (nkt == 1: the same tile again, into a stage that is never read)
         __syncthreads();
         int cur = 0;
         {
@@ -276,7 +291,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             for (int kt = 0; kt < nkt; ++kt) {
                 const int nxt = (cur == STAGES - 1) ? 0 : cur + 1;
                 const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
-                const bool do_dma = kt + 2 < nkt;
+                advance(kt + 3 < nkt);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int ps = p, ns = p ^ 1;
@@ -290,7 +305,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                         else if (m < 10) pa[ns][0][m - 8] = rdA(nbuf, nk, m - 8);
                         else if (m == 10) pw[ns][0] = rdW(nbuf, nk);
                         else if (m == 11) pw[ns][1] = rdW(nbuf, nk + 1);
-                        else { if (p == 1 && do_dma) dma_piece(kt + 2, dstage, m - 12); }
+                        else { if (p == 1) dma_piece(dstage, m - 12); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // ---- odd step: remaining fragments of the next pair, last DMA piece, the 4 multiplies in one cluster
@@ -300,7 +315,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                         acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][1][i], pb[ps][1][j], acc[m >> 2][m & 3], 0, 0, 0);
                         if (m < 2) pa[ns][1][m] = rdA(nbuf, nk + 1, m);
                         else if (m < 10) pb[ns][0][m - 2] = rdB(nbuf, nk, m - 2);
-                        else if (m == 10) { if (p == 1 && do_dma) dma_piece(kt + 2, dstage, 4); }
+                        else if (m == 10) { if (p == 1) dma_piece(dstage, 4); }
                         else if (m == 13) {
 #pragma unroll
                             for (int q = 0; q < 2; ++q) { pa[ns][0][q] *= pw[ns][0]; pa[ns][1][q] *= pw[ns][1]; }
@@ -424,6 +439,187 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64_persistent(Pgl
     }
 }
 
+// ---- the Gram with INDEPENDENT workgroups on a SIMD ("fine" pipeline).  In the 8-wave Gram above the two waves of a SIMD belong to
+// one workgroup: they reach every barrier and every DMA wait together, and the MFMA pipe idles while they do (rocprofv3:
+// SQ_VALU_MFMA_BUSY_CYCLES = 90.6 % with 18 % of the wave cycles in s_waitcnt).  Here a workgroup is 4 waves (one neuron's 128 x 128
+// tile, 32 x 128 per wave) and TWO workgroups share a CU, so the waves that alternate on a SIMD stall independently.  To fit twice
+// in LDS the stages are 8 rows deep (one pair of k-steps), four of them: tile kt+3 is requested during pair kt and published by
+// the barrier at the end of pair kt+1.  Same fragment/DMA slotting as the pipeline above; 5 DMA pieces per wave per pair.
+constexpr int FK = 8, FST = 4, FSA = 128 + PAD;
+constexpr int F_A = FK * FSA, F_B = FK * FSA, F_W = FK;
+constexpr int F_STAGE = F_A + F_B + F_W;
+constexpr size_t F_LDS = (size_t)FST * F_STAGE * sizeof(double) + 16;
+
+__device__ __forceinline__ void gram_fine_item(const PglGemmArgs& g, const long w, double* smem) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int nz = g.nz_total;
+    const int tile = (int)(w / nz), z = (int)(w % nz);
+    const int tm = isqrt_tri(tile), tn = tile - tm * (tm + 1) / 2;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int nkt = g.K / FK;
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int frow = lane >> 4, fcol = lane & 15;
+    const double* __restrict__ Ab = g.A;
+    const double* __restrict__ Bb = g.B;
+
+    const int wv = __builtin_amdgcn_readfirstlane(wq);
+    const char* gp[5];
+    long gstep[5], gadv[5];
+    int loff[5];
+    {
+        int ca = m0 + lane * 2, cb = n0 + lane * 2;
+        ca = ca < g.a_cols ? ca : g.a_cols - 2;
+        cb = cb < g.b_cols ? cb : g.b_cols - 2;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = wv + 4 * (p >> 1);
+            if ((p & 1) == 0) { gp[p] = reinterpret_cast<const char*>(Ab + (long)r * g.lda + ca); gstep[p] = (long)FK * g.lda * 8; loff[p] = r * FSA * 8; }
+            else { gp[p] = reinterpret_cast<const char*>(Bb + (long)r * g.ldb + cb); gstep[p] = (long)FK * g.ldb * 8; loff[p] = (F_A + r * FSA) * 8; }
+        }
+        const int dw = wv * 4 + (lane & 3), r = dw >> 1;      // 8 weights = 16 dwords, 4 per wave
+        gp[4] = reinterpret_cast<const char*>(g.W + (long)r * g.ldw + z) + 4 * (dw & 1);
+        gstep[4] = (long)FK * g.ldw * 8;
+        loff[4] = (F_A + F_B) * 8 + wv * 16;
+    }
+    auto advance = [&](bool adv) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) gadv[p] = adv ? gstep[p] : 0;
+    };
+    auto dma_piece = [&](int stage, int p) {
+        char* dst = reinterpret_cast<char*>(smem) + (size_t)stage * F_STAGE * 8 + loff[p];
+        if (p < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[p], (lds_ptr_t)dst, 16, 0, 0);
+        else if (lane < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[4], (lds_ptr_t)dst, 4, 0, 0);
+        gp[p] += gadv[p];
+    };
+    auto dma = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) dma_piece(stage, p);
+    };
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    advance(1 < nkt); dma(0);
+    advance(2 < nkt); dma(1);
+    advance(3 < nkt); dma(2);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // tiles 0 and 1 have landed
+    block_sync_lds();
+
+    double pa[2][2][2], pb[2][2][8], pw[2][2];       // [set][step in pair][fragment]
+    auto rdA = [&](int buf, int kk, int i) { return smem[buf * F_STAGE + wq * 32 + fcol + (kk * 4 + frow) * FSA + i * 16]; };
+    auto rdB = [&](int buf, int kk, int j) { return smem[buf * F_STAGE + F_A + fcol + (kk * 4 + frow) * FSA + j * 16]; };
+    auto rdW = [&](int buf, int kk) { return smem[buf * F_STAGE + F_A + F_B + kk * 4 + frow]; };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pa[0][0][i] = rdA(0, 0, i); pa[0][1][i] = rdA(0, 1, i); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pb[0][0][j] = rdB(0, 0, j);
+    pw[0][0] = rdW(0, 0); pw[0][1] = rdW(0, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pa[0][0][i] *= pw[0][0]; pa[0][1][i] *= pw[0][1]; }
+
+    int cur = 0;
+    for (int kt0 = 0; kt0 < nkt; kt0 += 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {                 // two pairs per trip so that the register sets alternate statically
+            const int kt = kt0 + p;
+            if (kt >= nkt) break;
+            const int ps = p, ns = p ^ 1;
+            const int nxt = (cur + 1) & (FST - 1), dstage = (cur + 3) & (FST - 1);
+            advance(kt + 4 < nkt);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int i = m >> 3, j = m & 7;
+                acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][0][i], pb[ps][0][j], acc[m >> 2][m & 3], 0, 0, 0);
+                if (m < 8) pb[ps][1][m] = rdB(cur, 1, m);
+                else if (m < 10) pa[ns][0][m - 8] = rdA(nxt, 0, m - 8);
+                else if (m == 10) pw[ns][0] = rdW(nxt, 0);
+                else if (m == 11) pw[ns][1] = rdW(nxt, 1);
+                else dma_piece(dstage, m - 12);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int i = m >> 3, j = m & 7;
+                acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ps][1][i], pb[ps][1][j], acc[m >> 2][m & 3], 0, 0, 0);
+                if (m < 2) pa[ns][1][m] = rdA(nxt, 1, m);
+                else if (m < 10) pb[ns][0][m - 2] = rdB(nxt, 0, m - 2);
+                else if (m == 10) dma_piece(dstage, 4);
+                else if (m == 13) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { pa[ns][0][q] *= pw[ns][0]; pa[ns][1][q] *= pw[ns][1]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // publish tile kt+2 (requested two pairs ago); this pair's 5 requests may stay in flight (past the end of K they
+            // re-request the last tile into a stage that is not read any more)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            block_sync_lds();
+            cur = nxt;
+        }
+    }
+
+    double* __restrict__ Cb = g.C + (long)z * g.strideC;
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double cv[4][4];
+        if (beta != 0.0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 4 * i + j;
+                    const int row = m0 + wq * 32 + (f >> 3) * 16 + frow + 4 * r, col = n0 + (f & 7) * 16 + fcol;
+                    cv[r][j] = (row < g.M && col < g.N) ? Cb[(long)row * g.ldc + col] : 0.0;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 4 * i + j;
+                const int row = m0 + wq * 32 + (f >> 3) * 16 + frow + 4 * r, col = n0 + (f & 7) * 16 + fcol;
+                if (row >= g.M || col >= g.N) continue;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * cv[r][j];
+                Cb[(long)row * g.ldc + col] = v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gram_fine_persistent(PglGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    long* ticket = reinterpret_cast<long*>(smem + (size_t)FST * F_STAGE);
+    const int ntm = (g.M + 127) / 128;
+    const long total = (long)ntm * (ntm + 1) / 2 * g.nz_total;
+    const long chunk = (total + 7) / 8;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long w = -1;
+            for (int hop = 0; hop < 8 && w < 0; ++hop) {
+                const int y = (int)((xcc + hop) & 7u);
+                const long lo = (long)y * chunk, hi = (lo + chunk < total) ? lo + chunk : total;
+                if (lo >= hi) continue;
+                const long it = atomicAdd(&g.sched[y], 1);
+                if (lo + it < hi) w = lo + it;
+            }
+            ticket[0] = w;
+        }
+        __syncthreads();
+        const long w = ticket[0];
+        if (w < 0) break;
+        gram_fine_item(g, w, smem);
+    }
+}
+
 template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2, bool CINIT = false>
 int launch(const PglGemmArgs& a, hipStream_t st) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
@@ -492,6 +688,30 @@ int launch_persistent(const PglGemmArgs& a0, hipStream_t st) {
     return PGL_OK;
 }
 
+static int launch_gram_fine(const PglGemmArgs& a0, hipStream_t st) {
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fine_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
+        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", F_LDS, hipGetErrorString(e)); return PGL_ERR_HIP; }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n_cu <= 0) n_cu = 256;
+        attr_set = true;
+    }
+    const int ntm = (a0.M + 127) / 128;
+    const long total = (long)ntm * (ntm + 1) / 2 * a0.nz_total;
+    if (total <= 0) return PGL_OK;
+    PglGemmArgs a = a0;
+    a.sched = sched_slot(st);
+    if (!a.sched) { pgl_set_error("persistent gemm: scheduler scratch unavailable"); return PGL_ERR_HIP; }
+    const long grid = total < 2L * n_cu ? total : 2L * n_cu;
+    hipLaunchKernelGGL(gram_fine_persistent, dim3((unsigned)grid), dim3(256), F_LDS, st, a);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
 }  // namespace
 
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
@@ -503,6 +723,18 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             // production: persistent, DMA-staged 3-stage pipeline; PGL_GRAM_STAGES=2 selects the generic 2-stage kernel (debugging aid)
             static const int variant = getenv("PGL_GRAM_STAGES") ? atoi(getenv("PGL_GRAM_STAGES")) : 3;
             if (variant == 2) return launch<2, 2, 2, true, 2>(a, st);
+            if (variant == 4) return launch_gram_fine(a, st);
+            // launches that cannot give every CU two 8-wave items (few neurons: small models, thin shards) run as 4-wave workgroups,
+            // one neuron each, two per CU: twice the items, and 53 vs 29 TFLOP/s at D = 640 with 16 neurons; at full size the
+            // 8-wave pipeline (two neurons share every staged X tile) is 5 % faster
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+            }
+            const long ntm = (a.M + 127) / 128;
+            if (variant == 3 && ntm * (ntm + 1) / 2 * a.nbatch < 2L * n_cu) return launch_gram_fine(a, st);
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
