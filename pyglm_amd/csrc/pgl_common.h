@@ -28,6 +28,7 @@ void pgl_set_error(const char* fmt, ...);
     } while (0)
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // ---- fp64 MFMA "TN" contraction (pgl_gemm.hip):  C[m][n] = beta*C + alpha * sum_k w[k] * A[k][m] * B[k][n]
 struct PglGemmArgs {

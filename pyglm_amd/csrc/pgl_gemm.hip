@@ -103,28 +103,44 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     const int zg = batch * WZ + wz;                   // weight column / output index of this wave
     const bool zvalid = !WEIGHTED || zg < g.nz_total;
 
-    // ---- loader geometry: a row of BM (BN) doubles is BM/2 (BN/2) 16-byte pieces
-    double2 ra[C::A_LD], rb[C::B_LD];
+    // ---- loader geometry: a row of BM (BN) doubles is BM/2 (BN/2) 16-byte pieces.  Every 16-byte load keeps a cursor that moves down
+    // one K tile per use (no per-load index arithmetic in the loop); columns beyond a_cols / b_cols are clamped to a readable pair:
+    // they only feed output rows / columns that are never stored.
+    d2_t ra[C::A_LD], rb[C::B_LD];                   // (ext-vector type: HIP's double2 struct ends up in scratch here)
     double rw = 0.0;
     const double asign = CINIT ? g.alpha : 1.0;     // CINIT: alpha = +-1 is folded into the A operand on its way to LDS
-    auto gload = [&](int kt) {
-        const long krow = (long)kt * BK;
+    unsigned oa_[C::A_LD], ob_[C::B_LD], ow_ = 0;                  // per-thread byte offsets inside a K tile (constant)
+    const char* ka_ = reinterpret_cast<const char*>(Ab);            // wave-uniform bases of the K tile to load next
+    const char* kb_ = reinterpret_cast<const char*>(Bb);
+    const char* kw_ = reinterpret_cast<const char*>(g.W);
 #pragma unroll
-        for (int i = 0; i < C::A_LD; ++i) {
-            const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-            const int col = m0 + c;
-            ra[i] = (col < g.a_cols) ? *reinterpret_cast<const double2*>(Ab + (krow + r) * g.lda + col) : double2{0.0, 0.0};
-        }
+    for (int i = 0; i < C::A_LD; ++i) {
+        const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
+        int col = m0 + c;
+        col = col < g.a_cols ? col : g.a_cols - 2;
+        oa_[i] = (unsigned)(((long)r * g.lda + col) * 8);
+    }
 #pragma unroll
-        for (int i = 0; i < C::B_LD; ++i) {
-            const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
-            const int col = n0 + c;
-            rb[i] = (col < g.b_cols) ? *reinterpret_cast<const double2*>(Bb + (krow + r) * g.ldb + col) : double2{0.0, 0.0};
-        }
-        if (WEIGHTED && tid < BK * WZ) {
-            const int r = tid / WZ, z = tid % WZ, zc = batch * WZ + z;
-            rw = (zc < g.nz_total) ? g.W[(krow + r) * g.ldw + zc] : 0.0;
-        }
+    for (int i = 0; i < C::B_LD; ++i) {
+        const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
+        int col = n0 + c;
+        col = col < g.b_cols ? col : g.b_cols - 2;
+        ob_[i] = (unsigned)(((long)r * g.ldb + col) * 8);
+    }
+    if (WEIGHTED) {
+        const int t_ = tid < BK * WZ ? tid : 0, r = t_ / WZ, z = t_ % WZ;
+        int zc = batch * WZ + z;
+        zc = zc < g.nz_total ? zc : g.nz_total - 1;
+        ow_ = (unsigned)(((long)r * g.ldw + zc) * 8);
+    }
+    const long stepA = (long)BK * g.lda * 8, stepB = (long)BK * g.ldb * 8, stepW = (long)BK * g.ldw * 8;
+    auto gload = [&](int) {
+#pragma unroll
+        for (int i = 0; i < C::A_LD; ++i) ra[i] = *reinterpret_cast<const d2_t*>(ka_ + oa_[i]);
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) rb[i] = *reinterpret_cast<const d2_t*>(kb_ + ob_[i]);
+        if (WEIGHTED && tid < BK * WZ) rw = *reinterpret_cast<const double*>(kw_ + ow_);
+        ka_ += stepA; kb_ += stepB; kw_ += stepW;
     };
     auto lstore = [&](int buf) {
         double* As = smem + buf * C::STAGE;
@@ -132,13 +148,13 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
         for (int i = 0; i < C::A_LD; ++i) {
             const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-            if constexpr (CINIT) *reinterpret_cast<double2*>(As + r * C::SA + c) = double2{ra[i].x * asign, ra[i].y * asign};
-            else *reinterpret_cast<double2*>(As + r * C::SA + c) = ra[i];
+            if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[i] * asign;
+            else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < C::B_LD; ++i) {
             const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
-            *reinterpret_cast<double2*>(Bs + r * C::SB + c) = rb[i];
+            *reinterpret_cast<d2_t*>(Bs + r * C::SB + c) = rb[i];
         }
         if (WEIGHTED && tid < BK * WZ) (Bs + C::B_ELEMS)[tid] = rw;
     };
