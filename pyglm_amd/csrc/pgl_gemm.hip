@@ -227,7 +227,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         // tile earlier) is published by the barrier after the first pair of k-steps of tile kt; the DMA of tile kt+2 then reuses the
         // stage last read in tile kt-1, which every wave had finished before it could pass the barrier.  Because tile kt+1 is
         // readable from the middle of tile kt on, the fragment pipeline never drains at a tile boundary.
-        static_assert(DMA && WEIGHTED && STAGES == 3, "the 3-stage pipeline is the DMA-staged weighted Gram");
+        static_assert(DMA && WEIGHTED && (STAGES == 3 || STAGES == 4), "the 3/4-stage pipeline is the DMA-staged weighted Gram");
         // DMA staging (global_load_lds): one wave-instruction moves one 1-KiB tile row straight into LDS (lane-linear
         // destination = exactly our row layout; the padded row stride only moves the per-instruction base).  Out-of-range
         // columns are clamped to a readable one: they only feed outputs that are never stored.
@@ -278,11 +278,16 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
             for (int p = 0; p < 5; ++p) dma_piece(stage, p);
         };
+        // (A fourth stage -- requests a whole tile earlier -- measured the same 72.8 TFLOP/s: request latency is not what is left.)
+        // prologue: tiles 0 .. STAGES-2 requested, tile 0 awaited (past the end of K a request repeats the last tile into a stage
+        // that is never read)
         advance(1 < nkt);
         dma(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         advance(2 < nkt);
-        dma(1);                      // (nkt == 1: the same tile again, into a stage that is never read)
+        dma(1);
+        if constexpr (STAGES == 4) { advance(3 < nkt); dma(2); }
+        if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __syncthreads();
         int cur = 0;
         {
@@ -306,8 +311,8 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             for (int i = 0; i < 2; ++i) { pa[0][0][i] *= pw[0][0]; pa[0][1][i] *= pw[0][1]; }
             for (int kt = 0; kt < nkt; ++kt) {
                 const int nxt = (cur == STAGES - 1) ? 0 : cur + 1;
-                const int dstage = (nxt == STAGES - 1) ? 0 : nxt + 1;
-                advance(kt + 3 < nkt);
+                const int dstage = (cur == 0) ? STAGES - 1 : cur - 1;          // the stage of tile kt-1 takes tile kt+STAGES-1
+                advance(kt + STAGES < nkt);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int ps = p, ns = p ^ 1;
@@ -339,7 +344,9 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (p == 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // tile kt+1 must have landed; with four stages the requests of tile kt+2 may stay in flight
+                        if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         block_sync_lds();
                     }
                 }
@@ -354,7 +361,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     const double alpha = g.alpha, beta = g.beta;
     // accumulator tile (i, j) of acc[4][4] -> offsets inside the workgroup tile: 64 x 64 wave tiles, or (wide Gram layout)
     // tile f = 4 i + j of a 32 x 128 wave tile
-    constexpr bool WIDE = STAGES == 3;
+    constexpr bool WIDE = STAGES >= 3;
     auto roff = [&](int i, int j) { return WIDE ? wmn * 32 + ((4 * i + j) >> 3) * 16 : wm * 64 + i * 16; };
     auto coff = [&](int i, int j) { return WIDE ? ((4 * i + j) & 7) * 16 : wn * 64 + j * 16; };
     if constexpr (CINIT) {
