@@ -272,7 +272,8 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             char* dst = reinterpret_cast<char*>(smem) + (size_t)stage * C::STAGE * 8 + loff[p];
             if (p < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[p], (lds_ptr_t)dst, 16, 0, 0);
             else if (lane < 8) __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[4], (lds_ptr_t)dst, 4, 0, 0);
-            gp[p] += gadv[p];
+            // the 64-bit add stays in this slot (left to the compiler, all five end up in one clump at the loop latch)
+            asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(gp[p]) : "v"(gp[p]), "s"(gadv[p]));
         };
         auto dma = [&](int stage) {
 #pragma unroll
@@ -286,6 +287,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         advance(2 < nkt);
         dma(1);
         if constexpr (STAGES == 4) { advance(3 < nkt); dma(2); }
+        advance(STAGES < nkt);
         if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __syncthreads();
@@ -312,7 +314,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             for (int kt = 0; kt < nkt; ++kt) {
                 const int nxt = (cur == STAGES - 1) ? 0 : cur + 1;
                 const int dstage = (cur == 0) ? STAGES - 1 : cur - 1;          // the stage of tile kt-1 takes tile kt+STAGES-1
-                advance(kt + STAGES < nkt);
+                if (kt + STAGES >= nkt) advance(false);                          // (taken for the last tiles only)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int ps = p, ns = p ^ 1;
