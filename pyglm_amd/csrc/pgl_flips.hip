@@ -293,48 +293,56 @@ __global__ __launch_bounds__(256) void gather_kk_kernel(FlipArgs g) {
     A[i * KMAX + j] = v;
 }
 
-// dst[o+i][o+j] = (src[o.., o..])^-1 for the 128 x 128 block at offset o (in-LDS symmetric sweeps; the block is definite)
+// dst[o+i][o+j] = (src[o.., o..])^-1 for the 128 x 128 block at offset o, by 128 in-order symmetric sweeps (the block is definite).
+// The matrix lives in REGISTERS: thread (tr, tc) = (tid / 128, tid % 128) owns column tc, rows tr, tr+2, ... (64 doubles); each step
+// publishes the pivot column through LDS (two owner threads write it, everyone reads it back as wave-wide broadcasts) and costs one
+// FMA per element.  (The first version kept the matrix in LDS and paid four dependent LDS accesses per element: 1.27 ms per block.)
 __global__ __launch_bounds__(256) void invert128_kernel(FlipArgs g, const double* src_base, double* dst_base, int o) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int k = g.d_cnt[n];
-    constexpr int kk = KB2, ld = KB2 + 1;
-    double* colp = lds;                       // [128]
-    double* A = lds + KB2;
+    constexpr int kk = KB2;
+    __shared__ double colp[2][kk];            // double-buffered pivot column
+    __shared__ int s_bad;
     const double* src = src_base + (size_t)n * KMAX * KMAX;
     double* dst = dst_base + (size_t)n * KMAX * KMAX;
     if (k <= o) {                             // nothing real in this block (the frame holds the identity there)
         for (int e = tid; e < kk * kk; e += 256) dst[(o + e / kk) * KMAX + o + e % kk] = (e / kk == e % kk) ? 1.0 : 0.0;
         return;
     }
-    for (int e = tid; e < kk * kk; e += 256) {
-        const int i = e / kk, j = e % kk;
-        A[i * ld + j] = src[(o + i) * KMAX + o + j];
+    const int tr = tid >> 7, tc = tid & (kk - 1);
+    double a[kk / 2];
+#pragma unroll
+    for (int r = 0; r < kk / 2; ++r) a[r] = src[(o + tr + 2 * r) * KMAX + o + tc];
+    if (tid == 0) s_bad = 0;
+    if (tc == 0) {
+#pragma unroll
+        for (int r = 0; r < kk / 2; ++r) colp[0][tr + 2 * r] = a[r];
     }
     __syncthreads();
-    __shared__ int s_bad;
-    if (tid == 0) s_bad = 0;
     for (int p = 0; p < kk; ++p) {
-        for (int i = tid; i < kk; i += 256) colp[i] = A[i * ld + p];
-        __syncthreads();
-        const double d = colp[p];
+        const double* cp = colp[p & 1];
+        const double d = cp[p];
         if (tid == 0 && !(d > 0.0)) s_bad = 1;
         const double inv = 1.0 / d;
-        for (int e = tid; e < kk * kk; e += 256) {
-            const int i = e / kk, j = e % kk;
+        const double cj = cp[tc] * inv;
+        const bool pivcol = tc == p;
+#pragma unroll
+        for (int r = 0; r < kk / 2; ++r) {
+            const int i = tr + 2 * r;
+            const double ci = cp[i];
             double v;
-            if (i == p && j == p) v = -inv;
-            else if (i == p) v = colp[j] * inv;
-            else if (j == p) v = colp[i] * inv;
-            else v = A[i * ld + j] - colp[i] * colp[j] * inv;
-            A[i * ld + j] = v;
+            if (pivcol) v = (i == p) ? -inv : ci * inv;
+            else v = (i == p) ? cj : a[r] - ci * cj;
+            a[r] = v;
+        }
+        if (tc == p + 1) {                    // the next pivot column, already updated
+#pragma unroll
+            for (int r = 0; r < kk / 2; ++r) colp[(p + 1) & 1][tr + 2 * r] = a[r];
         }
         __syncthreads();
     }
-    for (int e = tid; e < kk * kk; e += 256) {
-        const int i = e / kk, j = e % kk;
-        dst[(o + i) * KMAX + o + j] = -A[i * ld + j];
-    }
+#pragma unroll
+    for (int r = 0; r < kk / 2; ++r) dst[(o + tr + 2 * r) * KMAX + o + tc] = -a[r];
     if (tid == 0 && s_bad) atomicOr(&g.status[n], 2);
 }
 
@@ -507,9 +515,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, hipStrea
     const int Md = s.N * s.B + 2;
     if (!have_G && max_pivots > KB2) {
         if (max_pivots > 2 * KB2) { pgl_set_error("flip_apply: %d pivots per call (max %d)", max_pivots, 2 * KB2); return PGL_ERR_ARG; }
-        static bool once2 = false;
-        const size_t lds128 = ((size_t)KB2 + KB2 * (KB2 + 1)) * sizeof(double);
-        if (!once2) { int rc = set_lds(reinterpret_cast<const void*>(invert128_kernel), lds128); if (rc) return rc; once2 = true; }
+        const size_t lds128 = 0;
         const long sq = (long)KMAX * KMAX;
         double* Akk = s.Lws;
         hipLaunchKernelGGL(gather_kk_kernel, dim3(2 * KB2 * 2 * KB2 / 256, s.nb), dim3(256), 0, st, g);
