@@ -101,6 +101,9 @@ typedef struct {
     double* Lws;                         /* [nb][(kmax+1)^2] scratch: sub-tableau of the current proposal window */
     double* Ut; double* Wt; long ldu;    /* [nb][kmax][ldu] scratch, ldu >= D+2, even */
     int* status;                         /* [nb] sticky flags: 1 non-PD block, 2 singular pivot, 4 non-PD posterior */
+    int visit_order;                     /* 0: tableau rows in J's order.  1: rows / columns in PROPOSAL order (position k = block perm[k];
+                                          * bias and potential rows last; built by pgl_flip_visit_order): d_idx are positions, and the
+                                          * update after window w touches only the rows not yet proposed */
 } pgl_flip_t;
 int pgl_flip_kmax(void);                         /* pivots (scalar rows) per tableau update */
 int pgl_flip_window_blocks(int B);               /* blocks proposed per window */
@@ -108,7 +111,11 @@ int pgl_flip_apply(const pgl_flip_t* s, void* hip_stream);              /* sweep
 /* same for lists of up to max_pivots <= 256 rows per neuron that are all switched ON (the pivot block is positive definite): the
  * initial sweep on the active set; the 256 x 256 pivot-block inverse is assembled from two in-LDS 128 x 128 inversions. Uses Lws. */
 int pgl_flip_apply_chunk(const pgl_flip_t* s, int max_pivots, void* hip_stream);
-int pgl_flip_apply_window(const pgl_flip_t* s, void* hip_stream);       /* same, right after pgl_flip_decide (which already left G = (M_DD)^-1) */
+/* same, right after pgl_flip_decide(window) (which already left G = (M_DD)^-1); with visit_order = 1 only the trailing square from
+ * position (window+1)*R on is updated -- rows of proposed blocks are never read again (nothing at all after the last window) */
+int pgl_flip_apply_window(const pgl_flip_t* s, int window, void* hip_stream);
+/* M[z] = P_z J[z] P_z' (lower triangle; P_z from perm[z]): the sweep tableau in proposal order, instead of a plain copy of J_post */
+int pgl_flip_visit_order(const pgl_flip_t* s, const double* J, long ldj_src, long strideJ, void* hip_stream);
 int pgl_flip_decide(const pgl_flip_t* s, int window, void* hip_stream); /* run one window of proposals; fills the pivot list */
 
 /* ---- weight conditional (pyglm/regression.py:323-340) ---------------------------------------------------------- */

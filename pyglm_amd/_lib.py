@@ -13,7 +13,7 @@ class FlipState(ctypes.Structure):   # pgl_flip_t
     _fields_ = [("M", c_p), ("ldj", c_l), ("strideM", c_l), ("nb", c_i), ("N", c_i), ("B", c_i),
                 ("perm", c_p), ("u", c_p), ("rho", c_p), ("c0", c_p), ("a", c_p), ("skip", c_p),
                 ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("G", c_p), ("Lws", c_p),
-                ("Ut", c_p), ("Wt", c_p), ("ldu", c_l), ("status", c_p)]
+                ("Ut", c_p), ("Wt", c_p), ("ldu", c_l), ("status", c_p), ("visit_order", c_i)]
 
 
 class CholState(ctypes.Structure):   # pgl_chol_t
@@ -42,7 +42,8 @@ SIGNATURES = {
     "pgl_flip_window_blocks": [c_i],
     "pgl_flip_apply": [ctypes.POINTER(FlipState), c_p],
     "pgl_flip_apply_chunk": [ctypes.POINTER(FlipState), c_i, c_p],
-    "pgl_flip_apply_window": [ctypes.POINTER(FlipState), c_p],
+    "pgl_flip_apply_window": [ctypes.POINTER(FlipState), c_i, c_p],
+    "pgl_flip_visit_order": [ctypes.POINTER(FlipState), c_p, c_l, c_l, c_p],
     "pgl_flip_decide": [ctypes.POINTER(FlipState), c_i, c_p],
     "pgl_active_index": [ctypes.POINTER(CholState), c_p],
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],

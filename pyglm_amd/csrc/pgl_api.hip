@@ -29,8 +29,10 @@ struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
+    int permuted;
 };
-int pgl_k_flip_apply(const PglFlipState&, int, int, hipStream_t);
+int pgl_k_flip_apply(const PglFlipState&, int, int, int, hipStream_t);
+int pgl_k_flip_permute(const PglFlipState&, const double*, long, long, hipStream_t);
 int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);
 int pgl_k_flip_kmax(void);
 int pgl_k_flip_window_blocks(int);
@@ -138,24 +140,30 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
 
 static PglFlipState to_state(const pgl_flip_t* s) {
     return PglFlipState{s->M, s->ldj, s->strideM, s->nb, s->N, s->B, s->perm, s->u, s->rho, s->c0, s->a, s->skip,
-                        s->d_idx, s->d_sign, s->d_cnt, s->batch_k, s->G, s->Lws, s->Ut, s->Wt, s->ldu, s->status};
+                        s->d_idx, s->d_sign, s->d_cnt, s->batch_k, s->G, s->Lws, s->Ut, s->Wt, s->ldu, s->status, s->visit_order};
 }
 int pgl_flip_kmax(void) { return pgl_k_flip_kmax(); }
 int pgl_flip_window_blocks(int B) { return pgl_k_flip_window_blocks(B); }
 int pgl_flip_apply(const pgl_flip_t* s, void* st) {
     PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Ut && s->Wt && s->status);
     PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0);
-    return pgl_k_flip_apply(to_state(s), 0, 128, ST(st));
+    return pgl_k_flip_apply(to_state(s), 0, 128, -1, ST(st));
 }
 int pgl_flip_apply_chunk(const pgl_flip_t* s, int max_pivots, void* st) {
     PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Lws && s->Ut && s->Wt && s->status);
     PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0 && max_pivots > 0);
-    return pgl_k_flip_apply(to_state(s), 0, max_pivots, ST(st));
+    return pgl_k_flip_apply(to_state(s), 0, max_pivots, -1, ST(st));
 }
-int pgl_flip_apply_window(const pgl_flip_t* s, void* st) {
+int pgl_flip_visit_order(const pgl_flip_t* s, const double* J, long ldj_src, long strideJ, void* st) {
+    PGL_CHECK_ARG(s && s->M && s->perm && J && s->visit_order && s->nb > 0 && ldj_src >= (long)s->N * s->B + 2 && s->ldj >= (long)s->N * s->B + 2);
+    PGL_CHECK_ARG(s->B >= 1 && s->B <= 32);
+    return pgl_k_flip_permute(to_state(s), J, ldj_src, strideJ, ST(st));
+}
+int pgl_flip_apply_window(const pgl_flip_t* s, int window, void* st) {
     PGL_CHECK_ARG(s && s->M && s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->G && s->Ut && s->Wt && s->status);
     PGL_CHECK_ARG(s->ldu >= (long)s->N * s->B + 2 && s->ldu % 2 == 0 && s->ldj >= (long)s->N * s->B + 2 && s->nb > 0);
-    return pgl_k_flip_apply(to_state(s), 1, 0, ST(st));
+    PGL_CHECK_ARG(window >= 0);
+    return pgl_k_flip_apply(to_state(s), 1, 0, window, ST(st));
 }
 int pgl_flip_decide(const pgl_flip_t* s, int window, void* st) {
     PGL_CHECK_ARG(s && s->M && s->perm && s->u && s->rho && s->c0 && s->a && s->d_idx && s->d_sign && s->d_cnt && s->status && s->Lws);

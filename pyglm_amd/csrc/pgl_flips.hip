@@ -43,6 +43,8 @@ struct FlipArgs {
     double* Lws;                                 // [nb][(KMAX+1)^2] window sub-tableau scratch
     double* Ut; double* Wt; long ldu;            // [nb][KMAX][ldu]
     int* status;                                 // [nb] sticky error flags (1 = non-PD block met)
+    int permuted;                                // 1: tableau rows/columns are in VISIT order (position k holds block perm[k]; bias, h last)
+    int c_begin;                                 // first column the pivot-row gather has to produce (trailing-only window updates)
 };
 
 __device__ __forceinline__ double tab_get(const double* M, long ld, int i, int j) { return i >= j ? M[(long)i * ld + j] : M[(long)j * ld + i]; }
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     const int* perm = g.perm + (long)n * N;
     for (int e = tid; e < nl * nl; e += nthr) {
         const int i = e / nl, j = e % nl;
-        const int gi = (i < nl - 1) ? perm[k0 + i / B] * B + i % B : D + 1;
-        const int gj = (j < nl - 1) ? perm[k0 + j / B] * B + j % B : D + 1;
+        const int gi = (i < nl - 1) ? (g.permuted ? k0 * B + i : perm[k0 + i / B] * B + i % B) : D + 1;
+        const int gj = (j < nl - 1) ? (g.permuted ? k0 * B + j : perm[k0 + j / B] * B + j % B) : D + 1;
         L[i * ldl + j] = tab_get(M, g.ldj, gi, gj);
     }
     __syncthreads();
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
         int cnt = 0;
         for (int k = 0; k < nblk; ++k)
             if (s_flipped[k]) {
-                const int m = perm[k0 + k];
+                const int m = g.permuted ? k0 + k : perm[k0 + k];
                 for (int b = 0; b < B; ++b) { g.d_idx[(long)n * KMAX + cnt] = m * B + b; g.d_sign[(long)n * KMAX + cnt] = (double)s_flipped[k]; ++cnt; }
             }
         g.d_cnt[n] = cnt;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void gather_panel_kernel(FlipArgs g) {
     const int k = g.d_cnt[n];
     if (k <= 0) return;
     const int kp = (k + 15) & ~15;
-    const int q0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+    const int q0 = blockIdx.y * GT, c0 = g.c_begin + blockIdx.x * GT;
     if (q0 >= kp) return;
     const int Md = g.N * g.B + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -479,6 +481,38 @@ __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
     }
 }
 
+// ------------------------------------------------------------------ tableau in visit order
+// M[n] = P J[n] P' (lower triangle), P = the neuron's proposal order: position k holds block perm[k]; the bias row D and the
+// potential row D+1 stay last.  Once a window of positions has been proposed its rows are never read again, so the rank-k update after
+// window w only has to touch the trailing square from position (w+1) R on (pgl_k_flip_apply, window form) -- a third of the
+// full-tableau work summed over the windows -- and a window's sub-tableau is a contiguous diagonal square.
+// One thread moves one B x B block (new block row by = blockIdx.y, new block column bx <= by); by == N: the two border rows.
+__global__ __launch_bounds__(256) void permute_tableau_kernel(FlipArgs g, const double* __restrict__ Jsrc, long lds_, long strideJ) {
+    const int n = blockIdx.z, N = g.N, B = g.B, D = N * B;
+    const int* perm = g.perm + (long)n * N;
+    const double* J = Jsrc + (long)n * strideJ;
+    double* M = g.M + (long)n * g.strideM;
+    const int by = blockIdx.y, bx = blockIdx.x * 256 + threadIdx.x;
+    if (by < N) {
+        if (bx > by) return;
+        const int ri = perm[by] * B, rj = perm[bx] * B;
+        for (int x = 0; x < B; ++x)
+            for (int y = 0; y < B; ++y) M[(long)(by * B + x) * g.ldj + bx * B + y] = tab_get(J, lds_, ri + x, rj + y);
+    } else {
+        if (bx < N) {
+            const int rj = perm[bx] * B;
+            for (int y = 0; y < B; ++y) {
+                M[(long)D * g.ldj + bx * B + y] = J[(long)D * lds_ + rj + y];
+                M[(long)(D + 1) * g.ldj + bx * B + y] = J[(long)(D + 1) * lds_ + rj + y];
+            }
+        } else if (bx == N) {
+            M[(long)D * g.ldj + D] = J[(long)D * lds_ + D];
+            M[(long)(D + 1) * g.ldj + D] = J[(long)(D + 1) * lds_ + D];
+            M[(long)(D + 1) * g.ldj + D + 1] = J[(long)(D + 1) * lds_ + D + 1];
+        }
+    }
+}
+
 }  // namespace
 
 size_t pgl_k_flip_lds_decide(int B, int R) {
@@ -497,6 +531,7 @@ struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
+    int permuted;
 };
 
 int pgl_k_flip_window_blocks(int B) {
@@ -506,13 +541,22 @@ int pgl_k_flip_window_blocks(int B) {
 }
 
 // apply the pivot list currently in (d_idx, d_sign, d_cnt) to every neuron's tableau
-int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, hipStream_t st) {
-    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, pgl_k_flip_window_blocks(s.B), s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status};
+// window >= 0 (visit-order tableau only): the pivots lie in proposal window `window`, whose rows -- like those of all earlier windows --
+// are dead afterwards: only the trailing square is updated, the pivot rows and columns are not rewritten.
+int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int window, hipStream_t st) {
+    const int R_ = pgl_k_flip_window_blocks(s.B);
+    const int Md_ = s.N * s.B + 2;
+    int r0 = 0;                      // first live row / column
+    if (window >= 0 && s.permuted) {
+        if ((long)(window + 1) * R_ >= s.N) return PGL_OK;          // last window: nothing is read afterwards
+        r0 = ((window + 1) * R_ * s.B) & ~1;
+    }
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R_, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, r0};
     const size_t lds_inv = ((size_t)KMAX + 128 * 129) * sizeof(double);
     static bool once = false;
     if (!once) { int rc = set_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv); if (rc) return rc; once = true; }
-    const int Md = s.N * s.B + 2;
+    const int Md = Md_;
     if (!have_G && max_pivots > KB2) {
         if (max_pivots > 2 * KB2) { pgl_set_error("flip_apply: %d pivots per call (max %d)", max_pivots, 2 * KB2); return PGL_ERR_ARG; }
         const size_t lds128 = 0;
@@ -544,26 +588,37 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, hipStrea
         hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);
         PGL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu + GT - 1) / GT), KMAX / GT, s.nb), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu - r0 + GT - 1) / GT), KMAX / GT, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
-    // Wt = G Ut   (K x ldu), then  M -= Wt' Ut  on lower-triangular tiles
+    // Wt = G Ut   (K x ldu), then  M -= Wt' Ut  on lower-triangular tiles (columns / rows from r0 on)
+    const int ncol = (int)s.ldu - r0;
     PglGemmArgs w{};
     w.A = s.G; w.lda = KMAX; w.strideA = (long)KMAX * KMAX;
-    w.B = s.Ut; w.ldb = s.ldu; w.strideB = (long)KMAX * s.ldu;
-    w.C = s.Wt; w.ldc = s.ldu; w.strideC = (long)KMAX * s.ldu;
-    w.M = KMAX; w.N = (int)s.ldu; w.K = KMAX; w.a_cols = KMAX; w.b_cols = (int)s.ldu; w.nbatch = s.nb; w.nz_total = 0;
+    w.B = s.Ut + r0; w.ldb = s.ldu; w.strideB = (long)KMAX * s.ldu;
+    w.C = s.Wt + r0; w.ldc = s.ldu; w.strideC = (long)KMAX * s.ldu;
+    w.M = KMAX; w.N = ncol; w.K = KMAX; w.a_cols = KMAX; w.b_cols = ncol; w.nbatch = s.nb; w.nz_total = 0;
     w.alpha = 1.0; w.beta = 0.0; w.tri = 0; w.batch_k = s.batch_k; w.batch_dim = s.batch_k; w.dim_off = 0; w.dim_mode = 2; w.W = nullptr; w.ldw = 0;   // only the first K rows of W are non-zero / used
     int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st);
     if (rc) return rc;
     PglGemmArgs t{};
-    t.A = s.Wt; t.lda = s.ldu; t.strideA = (long)KMAX * s.ldu;
-    t.B = s.Ut; t.ldb = s.ldu; t.strideB = (long)KMAX * s.ldu;
-    t.C = s.M; t.ldc = s.ldj; t.strideC = s.strideM;
-    t.M = Md; t.N = Md; t.K = KMAX; t.a_cols = (int)s.ldu; t.b_cols = (int)s.ldu; t.nbatch = s.nb; t.nz_total = 0;
+    t.A = s.Wt + r0; t.lda = s.ldu; t.strideA = (long)KMAX * s.ldu;
+    t.B = s.Ut + r0; t.ldb = s.ldu; t.strideB = (long)KMAX * s.ldu;
+    t.C = s.M + (long)r0 * s.ldj + r0; t.ldc = s.ldj; t.strideC = s.strideM;
+    t.M = Md - r0; t.N = Md - r0; t.K = KMAX; t.a_cols = ncol; t.b_cols = ncol; t.nbatch = s.nb; t.nz_total = 0;
     t.alpha = -1.0; t.beta = 1.0; t.tri = 1; t.batch_k = s.batch_k; t.batch_dim = nullptr; t.dim_off = 0; t.W = nullptr; t.ldw = 0;
     rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(fixup_kernel, dim3((Md + GT - 1) / GT, KMAX / GT, s.nb), dim3(256), 0, st, g);
+    if (r0 == 0) {                   // (trailing form: the pivot rows / columns are dead, nothing to rewrite)
+        hipLaunchKernelGGL(fixup_kernel, dim3((Md + GT - 1) / GT, KMAX / GT, s.nb), dim3(256), 0, st, g);
+        PGL_CHECK_LAUNCH();
+    }
+    return PGL_OK;
+}
+
+int pgl_k_flip_permute(const PglFlipState& s, const double* J, long ldjs, long strideJ, hipStream_t st) {
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, 0, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, 1, 0};
+    hipLaunchKernelGGL(permute_tableau_kernel, dim3((s.N + 1 + 255) / 256, s.N + 1, s.nb), dim3(256), 0, st, g, J, ldjs, strideJ);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
@@ -572,7 +627,7 @@ int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
     const int R = pgl_k_flip_window_blocks(s.B);
     if (R < 1) { pgl_set_error("B=%d exceeds the window capacity %d", s.B, KWIN); return PGL_ERR_ARG; }
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status};
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, 0};
     const size_t lds = pgl_k_flip_lds_decide(s.B, R);
     static size_t lds_set = 0;
     if (lds > lds_set) { int rc = set_lds(reinterpret_cast<const void*>(decide_kernel), lds); if (rc) return rc; lds_set = lds; }

@@ -82,7 +82,7 @@ class GibbsEngine(object):
     OBS = {"bernoulli": 0, "negbin": 1, "gaussian": 2}
 
     def __init__(self, N, B, n0=0, n1=None, device="cuda:0", obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None,
-                 design_only=False):
+                 design_only=False, visit_order=True):
         if not torch.cuda.is_available():
             raise _lib.PglError("pyglm_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         _lib.load()
@@ -109,6 +109,9 @@ class GibbsEngine(object):
             batch = max(2, min(self.nloc, budget // per_neuron))
         self.nb = int(min(batch, self.nloc))
         self.design_only = design_only
+        # sweep tableau kept in proposal order (updates after a window touch only the rows not yet proposed); False keeps J's order and
+        # full-tableau updates -- same decisions, and the final tableau is then the complete sweep(A, S) (used by a full-size test)
+        self.visit_order = bool(visit_order)
         if not design_only:
             self._alloc_batch()
         self.timings = {}
@@ -323,6 +326,7 @@ class GibbsEngine(object):
             arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
             dev[k] = torch.from_numpy(arr).to(self.dev)
         dev["label"] = None if label is None else torch.from_numpy(label).to(self.dev)
+        dev["perm_host"] = np.ascontiguousarray(perm, dtype=np.int32)
         skip = torch.from_numpy(det.astype(np.int32)).to(self.dev)
         # One batch after the other on the current stream.  (Running batch k's flips / weight draw on a second stream behind batch
         # k+1's Gram was tried: bit-identical but no faster -- both stages compete for CU time)
@@ -378,17 +382,22 @@ class GibbsEngine(object):
         # ---- collapsed flips (regression.py:282-320)
         hf = self._tic("flips")
         if not det[s:s + nbb].all():
-            self.Mtab[:nbb].copy_(self.Jbuf[:nbb])
+            vo = int(self.visit_order)
             fs = FlipState(ptr(self.Mtab), ldj, strideJ, nbb, N, B, off4(dev["perm"], s * N), off8(dev["u"], s * N), off8(dev["rho"], s * N),
                            off8(dev["c0"], s * N), off4(self.a_dev, s * N), off4(skip, s), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt),
-                           ptr(self.batch_k), ptr(self.G), ptr(self.Lws), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s))
-            # initial sweep on S0 = {bias} U {active blocks}, in chunks of kmax pivots
+                           ptr(self.batch_k), ptr(self.G), ptr(self.Lws), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s), vo)
+            if vo:
+                call("pgl_flip_visit_order", ctypes.byref(fs), ptr(self.Jbuf), ldj, strideJ, st)
+            else:
+                self.Mtab[:nbb].copy_(self.Jbuf[:nbb])
+            # initial sweep on S0 = {bias} U {active blocks}, in chunks of kmax pivots (rows named by position in visit order)
             lists = []
             for i in range(nbb):
                 if det[s + i]:
                     lists.append(np.zeros(0, dtype=np.int32))
                 else:
-                    blocks = np.nonzero(a_host[s + i])[0]
+                    act = a_host[s + i]
+                    blocks = np.nonzero(act[dev["perm_host"][s + i]])[0] if vo else np.nonzero(act)[0]
                     rows = (blocks[:, None] * B + np.arange(B)[None, :]).ravel()
                     lists.append(np.concatenate(([D], rows)).astype(np.int32))
             ck = 256                                     # pivots per initial chunk (pgl_flip_apply_chunk: 2 x 2 blocks of 128)
@@ -412,7 +421,7 @@ class GibbsEngine(object):
                 call("pgl_flip_decide", ctypes.byref(fs), w, st)
                 self._toc(h2)
                 h2 = self._tic("flips.apply")
-                call("pgl_flip_apply_window", ctypes.byref(fs), st)
+                call("pgl_flip_apply_window", ctypes.byref(fs), w, st)
                 self._toc(h2)
         self._toc(hf)
         hc_ = self._tic("weights")

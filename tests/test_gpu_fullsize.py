@@ -146,7 +146,7 @@ def test_cfg5_shape_sweep_with_flips():
     torch.cuda.empty_cache()
     N, B, T, nloc = 4096, 8, 200000, 2
     basis, Y, rng = _problem(N, B, T)
-    eng = GibbsEngine(N, B, 0, nloc, batch=nloc)
+    eng = GibbsEngine(N, B, 0, nloc, batch=nloc, visit_order=False)     # J's row order + full-tableau updates: the final tableau is sweep(A, S)
     eng.add_data(Y, basis=basis)
     a = rng.random((nloc, N)) < 0.5
     W = rng.standard_normal((nloc, N, B)) * 0.05 * a[:, :, None]

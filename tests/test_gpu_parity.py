@@ -243,6 +243,38 @@ def test_sweep_vs_oracle_large_initial_active_set(torch_dev):
     assert (a1 != a).sum() > 100
 
 
+def test_visit_order_and_plain_tableau_agree(torch_dev):
+    """the tableau in proposal order with trailing-only window updates (default) and the plain one (J's order, full updates) take
+    the same decisions and draw the same weights; several windows (N = 150 > 64 blocks per window at B = 5)"""
+    from pyglm_amd.engine import make_draws
+    N, B, T = 150, 5, 2500
+    basis, X, Y, rng = _random_problem(N, B, T, seed=9)
+    kw = dict(rho=0.5, S_w=0.05, mu_w=0.0, mu_b=-1.5, S_b=2.0)          # a tight slab: many flips per window
+    a = rng.random((N, N)) < 0.6
+    W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
+    b = rng.standard_normal(N) - 1.5
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    rho_a, Jw, hw, Jb, hb, c0 = _hyp(regs)
+    perm, u, z = make_draws(31, 2, range(N), N, N * B)
+    outs = []
+    for vo in (True, False):
+        eng = _engine(N, B, batch=40, visit_order=vo)
+        eng.add_data(Y, X=X)
+        outs.append(eng.sweep(a, W, b, rho_a, Jw, hw, Jb, hb, c0, perm, u, z, seed=31, sweep=2)[:3])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-9, atol=1e-12)
+    assert (outs[0][0] != a).sum() > 1000
+    # and against the oracle for a few rows
+    omegas = eng.datasets[0].OK[:T, :N].cpu().numpy()
+    for n in (0, 77, N - 1):
+        r = orc.Regression(N, B, **kw)
+        r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+        r.resample([(X, Y[:, n])], [omegas[:, n]], perm[n], u[n], z[n])
+        np.testing.assert_array_equal(outs[0][0][n], r.a)
+        np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
+
+
 def test_sharded_equals_unsharded(torch_dev):
     """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit"""
     from pyglm_amd.engine import make_draws
