@@ -486,29 +486,34 @@ __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
 // potential row D+1 stay last.  Once a window of positions has been proposed its rows are never read again, so the rank-k update after
 // window w only has to touch the trailing square from position (w+1) R on (pgl_k_flip_apply, window form) -- a third of the
 // full-tableau work summed over the windows -- and a window's sub-tableau is a contiguous diagonal square.
-// One thread moves one B x B block (new block row by = blockIdx.y, new block column bx <= by); by == N: the two border rows.
+// One workgroup moves one SOURCE block row mi (B rows of J, columns up to its diagonal block): the reads are coalesced row segments and
+// J is read exactly once; a thread owns one source column (block mj, offset y) and writes its B values either as B row segments of the
+// destination block (pos[mi], pos[mj]) or, when that block lies above the diagonal, as one contiguous run of its transpose
+// (pos[mj], pos[mi]).  blockIdx.y == N / N + 1: the bias and potential rows.  pos = inverse of perm, built in LDS per workgroup.
 __global__ __launch_bounds__(256) void permute_tableau_kernel(FlipArgs g, const double* __restrict__ Jsrc, long lds_, long strideJ) {
+    extern __shared__ int s_pos[];              // [N]
     const int n = blockIdx.z, N = g.N, B = g.B, D = N * B;
     const int* perm = g.perm + (long)n * N;
     const double* J = Jsrc + (long)n * strideJ;
     double* M = g.M + (long)n * g.strideM;
-    const int by = blockIdx.y, bx = blockIdx.x * 256 + threadIdx.x;
-    if (by < N) {
-        if (bx > by) return;
-        const int ri = perm[by] * B, rj = perm[bx] * B;
-        for (int x = 0; x < B; ++x)
-            for (int y = 0; y < B; ++y) M[(long)(by * B + x) * g.ldj + bx * B + y] = tab_get(J, lds_, ri + x, rj + y);
+    for (int k = threadIdx.x; k < N; k += 256) s_pos[perm[k]] = k;
+    __syncthreads();
+    const int mi = blockIdx.y;
+    if (mi < N) {
+        const int pi = s_pos[mi], ncol = (mi + 1) * B;
+        for (int c = threadIdx.x; c < ncol; c += 256) {
+            const int mj = c / B, y = c - mj * B, pj = s_pos[mj];
+            double v[32];
+            for (int x = 0; x < B; ++x) v[x] = tab_get(J, lds_, mi * B + x, c);      // (diagonal block: mirrored above its diagonal)
+            if (pi >= pj) { for (int x = 0; x < B; ++x) M[(long)(pi * B + x) * g.ldj + pj * B + y] = v[x]; }
+            else { for (int x = 0; x < B; ++x) M[(long)(pj * B + y) * g.ldj + pi * B + x] = v[x]; }
+        }
     } else {
-        if (bx < N) {
-            const int rj = perm[bx] * B;
-            for (int y = 0; y < B; ++y) {
-                M[(long)D * g.ldj + bx * B + y] = J[(long)D * lds_ + rj + y];
-                M[(long)(D + 1) * g.ldj + bx * B + y] = J[(long)(D + 1) * lds_ + rj + y];
-            }
-        } else if (bx == N) {
-            M[(long)D * g.ldj + D] = J[(long)D * lds_ + D];
-            M[(long)(D + 1) * g.ldj + D] = J[(long)(D + 1) * lds_ + D];
-            M[(long)(D + 1) * g.ldj + D + 1] = J[(long)(D + 1) * lds_ + D + 1];
+        const int row = D + (mi - N);            // D: bias row, D + 1: potential row
+        for (int c = threadIdx.x; c <= row; c += 256) {
+            const double v = J[(long)row * lds_ + c];
+            const int pc = c < D ? s_pos[c / B] * B + c % B : c;
+            M[(long)row * g.ldj + pc] = v;
         }
     }
 }
@@ -618,7 +623,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
 int pgl_k_flip_permute(const PglFlipState& s, const double* J, long ldjs, long strideJ, hipStream_t st) {
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, 0, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
                s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, 1, 0};
-    hipLaunchKernelGGL(permute_tableau_kernel, dim3((s.N + 1 + 255) / 256, s.N + 1, s.nb), dim3(256), 0, st, g, J, ldjs, strideJ);
+    hipLaunchKernelGGL(permute_tableau_kernel, dim3(1, s.N + 2, s.nb), dim3(256), (size_t)s.N * sizeof(int), st, g, J, ldjs, strideJ);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
