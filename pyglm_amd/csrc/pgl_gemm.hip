@@ -210,17 +210,72 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     };
 
     if constexpr (STAGES == 2) {
-        // two LDS stages, one barrier at the end of every K tile
+        // two LDS stages, one barrier at the end of every K tile.  In the unweighted kernels (rank-k updates, activation, panel
+        // products: short K, two workgroups per CU running the same code in phase) the next tile's global loads ride in the MFMA
+        // shadows of the first k-step and its LDS stores in those of the last one, one request per MFMA, instead of standing as two
+        // blocks of ~40 instructions between the MFMA bursts.
         gload(0);
         lstore(0);
         __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nkt) gload(kt + 1);
+        if constexpr (!WEIGHTED) {
+            constexpr int NLD = C::A_LD + C::B_LD;
+            static_assert(NLD <= 16, "one staged load per MFMA slot of a k-step");
+            auto gload_piece = [&](int q) {
+                if (q < C::A_LD) ra[q] = *reinterpret_cast<const d2_t*>(ka_ + oa_[q]);
+                else rb[q - C::A_LD] = *reinterpret_cast<const d2_t*>(kb_ + ob_[q - C::A_LD]);
+            };
+            auto lstore_piece = [&](int buf, int q) {
+                double* As = smem + buf * C::STAGE;
+                double* Bs = As + C::A_ELEMS;
+                if (q < C::A_LD) {
+                    const int p = tid + q * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
+                    if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[q] * asign;
+                    else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[q];
+                } else {
+                    const int i = q - C::A_LD;
+                    const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
+                    *reinterpret_cast<d2_t*>(Bs + r * C::SB + c) = rb[i];
+                }
+            };
+            auto kstep = [&](int buf, int kk, auto hook) {
+                const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
+                const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
+                const int kr = kk * 4 + frow;
+                double a[4], b[4];
 #pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
-            if (kt + 1 < nkt) lstore(buf ^ 1);
-            __syncthreads();
+                for (int i = 0; i < 4; ++i) a[i] = As[kr * C::SA + i * 16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = Bs[kr * C::SB + j * 16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m >> 2], b[m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+                    hook(m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            for (int kt = 0; kt + 1 < nkt; ++kt) {
+                const int buf = kt & 1;
+                kstep(buf, 0, [&](int m) { if (m < NLD) gload_piece(m); });
+                ka_ += stepA; kb_ += stepB;
+                compute(buf, 1);
+                compute(buf, 2);
+                kstep(buf, 3, [&](int m) { if (m >= 16 - NLD) lstore_piece(buf ^ 1, m - (16 - NLD)); });
+                __syncthreads();
+            }
+            {
+                const int buf = (nkt - 1) & 1;
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
+            }
+        } else {
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int buf = kt & 1;
+                if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
+                if (kt + 1 < nkt) lstore(buf ^ 1);
+                __syncthreads();
+            }
         }
     } else {
         // ---- the Gram pipeline: three LDS stages filled by DMA, the barrier in the MIDDLE of a K tile.  Tile kt+1 (issued a whole
