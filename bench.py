@@ -99,12 +99,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world)
+    # test hooks for boxes with a single GPU: PGL_BENCH_DEVICE puts every rank on one device, PGL_DIST_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device) -- the launch path, sharding, gathers and the max-over-ranks timing are then the real ones
+    if os.environ.get("PGL_BENCH_DEVICE"):
+        local = int(os.environ["PGL_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     use_dist = world > 1 or bool(os.environ.get("PGL_FORCE_DIST"))   # PGL_FORCE_DIST: exercise the RCCL path with one rank
+    backend = os.environ.get("PGL_DIST_BACKEND", "nccl")
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM, SparseGaussianGLM
     N, B, T, L = cfg["N"], cfg["B"], cfg["T"], cfg["L"]
@@ -143,7 +151,7 @@ def main():
     stages = model.engine.collect_timings()
     model.engine.profile = False
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ll = model.log_likelihood()

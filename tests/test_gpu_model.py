@@ -248,3 +248,54 @@ def test_long_chain_matches_oracle_chain_statistically():
     np.testing.assert_allclose(np.diag(W1), np.diag(W2), atol=0.4)
     np.testing.assert_allclose(b1, b2, atol=0.25)
     assert np.abs(A1 - A2).max() < 0.35
+
+
+def _two_rank_worker(rank, world, port, out_path):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import torch.distributed as dist
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.utils.basis import cosine_basis
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    np.random.seed(0)
+    N, B, T = 9, 2, 1200
+    basis = cosine_basis(B, L=10) / 10
+    Y = (np.random.rand(T, N) < 0.2).astype(float)
+    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=5.0, mu_b=-1.0), seed=11, device="cuda:0")
+    model.add_data(Y)
+    lls = [model.log_likelihood()]
+    for _ in range(3):
+        model.resample_model()
+        lls.append(model.log_likelihood())
+    if rank == 0:
+        np.savez(out_path, A=model.adjacency, W=model.weights, b=model.biases, lls=np.array(lls), means=model.means[0])
+    else:
+        _ = model.means                       # (collective: every rank takes part in the gathers)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_sharing_the_gpu_equal_one(tmp_path):
+    """the N > 1 path on the real engine: two processes (gloo for the host collectives, both on cuda:0) shard the neurons 5 + 4;
+    state, log-likelihoods and means must equal the single-process run bit for bit (draws are keyed by the global neuron index)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_two_rank_worker, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, two), nprocs=2, join=True)
+    a, b = np.load(one), np.load(two)
+    for k in a.files:
+        if k == "lls":
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-13)      # sum over neurons in a different grouping
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
