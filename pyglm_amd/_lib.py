@@ -36,6 +36,11 @@ SIGNATURES = {
     "pgl_gaussian_stats": [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p],
     "pgl_scaled_gram": [c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_i, c_p],
     "pgl_weighted_gram": [c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_p],
+    "pgl_i8_plane_bytes": [c_i, c_i],
+    "pgl_i8_residue_bytes": [c_i],
+    "pgl_i8_colmax": [c_p, c_l, c_i, c_i, c_p, c_p],
+    "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "pgl_i8_gram": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
     "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "pgl_flip_kmax": [],
@@ -68,7 +73,8 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the export is missing
         fn.argtypes = args
-        fn.restype = ctypes.c_char_p if name == "pgl_last_error" else ctypes.c_int
+        fn.restype = (ctypes.c_char_p if name == "pgl_last_error" else ctypes.c_size_t if name in ("pgl_i8_plane_bytes", "pgl_i8_residue_bytes")
+                      else ctypes.c_int)
     if lib.pgl_abi_version() != 1:
         raise PglError("libpyglm_hip.so ABI version %d != 1" % lib.pgl_abi_version())
     _lib = lib

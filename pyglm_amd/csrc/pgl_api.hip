@@ -25,6 +25,11 @@ int pgl_k_basis_conv(const double*, long, const double*, double*, long, double*,
 int pgl_k_transpose(const double*, long, double*, long, int, int, hipStream_t);
 int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const int*, const double*,
                         const double*, int, int, int, hipStream_t);
+size_t pgl_k_i8_plane_bytes(int, int);
+size_t pgl_k_i8_residue_bytes(int);
+int pgl_k_i8_colmax(const double*, long, int, int, double*, hipStream_t);
+int pgl_k_i8_planes(const double*, long, const double*, long, const double*, const double*, int8_t*, int, int, int, hipStream_t);
+int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
 struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
@@ -136,6 +141,26 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
     PGL_CHECK_ARG(J && border_omega && border_kappa && Jw && hw && Jb && hb && nb > 0 && N > 0 && B > 0);
     PGL_CHECK_ARG(ldj >= (long)N * B + 2 && ldb >= (long)N * B + 1);
     return pgl_k_assemble_post(J, ldj, strideJ, border_omega, border_kappa, ldb, Jw, hw, label, Jb, hb, nb, N, B, ST(st));
+}
+
+// ---- integer-MFMA Gram (opt-in alternative to pgl_weighted_gram)
+size_t pgl_i8_plane_bytes(int D, int T) { return pgl_k_i8_plane_bytes(D, T); }
+size_t pgl_i8_residue_bytes(int D) { return pgl_k_i8_residue_bytes(D); }
+int pgl_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, void* st) {
+    PGL_CHECK_ARG(V && out && T > 0 && ncol > 0 && ldv >= ncol);
+    return pgl_k_i8_colmax(V, ldv, T, ncol, out, ST(st));
+}
+int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* xmax, const double* wmax, void* planes, int T, int D, int G,
+                  void* st) {
+    PGL_CHECK_ARG(X && xmax && planes && T > 0 && D > 0 && G > 0 && ldx >= D && (Om == nullptr || (wmax != nullptr && ldo >= G)));
+    PGL_CHECK_ARG(Om != nullptr || G == 1);
+    return pgl_k_i8_planes(X, ldx, Om, ldo, xmax, wmax, static_cast<int8_t*>(planes), T, D, G, ST(st));
+}
+int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ,
+                int T, int D, int G, int accumulate, void* st) {
+    PGL_CHECK_ARG(planes_x && planes_wx && residues && xmax && wmax && J && T > 0 && D > 0 && G > 0 && ldj >= D);
+    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), xmax, wmax, J, ldj,
+                         strideJ, T, D, G, accumulate, ST(st));
 }
 
 static PglFlipState to_state(const pgl_flip_t* s) {

@@ -1,0 +1,123 @@
+"""The integer-MFMA Gram (pgl_i8_*: opt-in alternative to pgl_weighted_gram) against NumPy integer arithmetic, against the fp64 kernel
+and against an extended-precision reference."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODULI = [255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193]
+BETA = 50
+
+
+def _scale_exp(m):
+    return np.where(m > 0, BETA - np.frexp(np.maximum(m, 1e-300))[1], 0).astype(np.int64)
+
+
+def _setup(T, D, G, seed=0):
+    import torch
+    from pyglm_amd._lib import call, ptr, load
+    rng = np.random.default_rng(seed)
+    X = rng.random((T, D)) * (rng.random((T, D)) < 0.3) * 0.2
+    X[:, 1] *= 1e-6                                           # a column on a very different scale
+    X[:, 2] = 0.0                                             # an empty column
+    Om = 0.25 * rng.gamma(4.0, 0.25, size=(T, G))
+    dev = torch.device("cuda:0")
+    Xd = torch.from_numpy(X).to(dev)
+    Od = torch.from_numpy(Om).to(dev)
+    xmax = torch.zeros(D, dtype=torch.float64, device=dev)
+    wmax = torch.zeros(G, dtype=torch.float64, device=dev)
+    call("pgl_i8_colmax", ptr(Xd), D, T, D, ptr(xmax), None)
+    call("pgl_i8_colmax", ptr(Od), G, T, G, ptr(wmax), None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(xmax.cpu().numpy(), np.abs(X).max(0))
+    np.testing.assert_array_equal(wmax.cpu().numpy(), Om.max(0))
+    return X, Om, Xd, Od, xmax, wmax
+
+
+def test_residue_planes_match_numpy():
+    import torch
+    from pyglm_amd._lib import call, ptr, load
+    T, D, G = 300, 37, 2
+    X, Om, Xd, Od, xmax, wmax = _setup(T, D, G)
+    lib = load()
+    Dq, Kp = 256, 320
+    assert lib.pgl_i8_plane_bytes(D, T) == 15 * Dq * Kp and lib.pgl_i8_residue_bytes(D) == 15 * Dq * Dq
+    PA = torch.full((15 * Dq * Kp,), 77, dtype=torch.int8, device="cuda:0")
+    PB = torch.full((G * 15 * Dq * Kp,), 77, dtype=torch.int8, device="cuda:0")
+    call("pgl_i8_planes", ptr(Xd), D, None, 0, ptr(xmax), None, ptr(PA), T, D, 1, None)
+    call("pgl_i8_planes", ptr(Xd), D, ptr(Od), G, ptr(xmax), ptr(wmax), ptr(PB), T, D, G, None)
+    torch.cuda.synchronize()
+    PA = PA.cpu().numpy().reshape(15, Dq, Kp).astype(np.int64)
+    PB = PB.cpu().numpy().reshape(G, 15, Dq, Kp).astype(np.int64)
+    eA = _scale_exp(np.abs(X).max(0))
+    IA = np.rint(np.ldexp(X, eA[None, :].astype(np.int32))).astype(np.int64)          # (T, D), |.| < 2^50
+    assert np.abs(IA).max() < 2 ** BETA
+    for q, p in enumerate(MODULI):
+        got = PA[q, :D, :T]
+        assert not ((got - IA.T) % p).any() and np.abs(got).max() <= p // 2            # a representative of the residue in [-p/2, p/2]
+        assert not PA[q, D:].any() and not PA[q, :, T:].any()                          # padding rows / time bins are zero
+    for g in range(G):
+        V = Om[:, g:g + 1] * X
+        fB = _scale_exp(Om[:, g].max() * np.abs(X).max(0))
+        IB = np.rint(np.ldexp(V, fB[None, :].astype(np.int32))).astype(np.int64)
+        for q in (0, 7, 14):
+            p = MODULI[q]
+            got = PB[g, q, :D, :T]
+            assert not ((got - IB.T) % p).any() and np.abs(got).max() <= p // 2
+
+
+@pytest.mark.parametrize("T,D,G", [(5000, 300, 3), (20000, 520, 2)])
+def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G):
+    import torch
+    from pyglm_amd._lib import call, ptr, load
+    X, Om, Xd, Od, xmax, wmax = _setup(T, D, G, seed=T)
+    lib = load()
+    dev = "cuda:0"
+    PA = torch.empty(lib.pgl_i8_plane_bytes(D, T), dtype=torch.int8, device=dev)
+    PB = torch.empty(G * lib.pgl_i8_plane_bytes(D, T), dtype=torch.int8, device=dev)
+    R = torch.empty(G * lib.pgl_i8_residue_bytes(D), dtype=torch.int8, device=dev)
+    ldj = (D + 2 + 15) // 16 * 16
+    J = torch.zeros(G, ldj, ldj, dtype=torch.float64, device=dev)
+    call("pgl_i8_planes", ptr(Xd), D, None, 0, ptr(xmax), None, ptr(PA), T, D, 1, None)
+    call("pgl_i8_planes", ptr(Xd), D, ptr(Od), G, ptr(xmax), ptr(wmax), ptr(PB), T, D, G, None)
+    call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 0, None)
+    torch.cuda.synchronize()
+    Ji = J.cpu().numpy()[:, :D, :D]
+    # (a) the exact integer answer: S = A'B on the scaled integers (Python ints), J = S 2^-(eA + fB)
+    eA = _scale_exp(np.abs(X).max(0))
+    IA = np.rint(np.ldexp(X, eA[None, :].astype(np.int32))).astype(np.int64)
+    for g in (0, G - 1):
+        fB = _scale_exp(Om[:, g].max() * np.abs(X).max(0))
+        IB = np.rint(np.ldexp(Om[:, g:g + 1] * X, fB[None, :].astype(np.int32))).astype(np.int64)
+        cols = [0, 1, 2, 5, D // 2, D - 1]
+        S = IA.astype(object).T.dot(IB[:, cols].astype(object))                       # exact big-integer product, (D, len(cols))
+        for k, j in enumerate(cols):
+            rows = np.arange(j, D)
+            want = np.array([float(S[i, k]) for i in rows]) * np.ldexp(1.0, -(eA[rows] + fB[j]).astype(np.int32))
+            np.testing.assert_allclose(Ji[g, rows, j], want, rtol=2e-15, atol=0)     # CRT + 14-step Horner: a few ulp of the exact value
+    # (b) against an extended-precision reference and the fp64 kernel: error relative to |a_i||b_j|
+    Xl = X.astype(np.longdouble)
+    Tp = (T + 15) // 16 * 16
+    Xp = torch.zeros(Tp, (D + 1 + 15) // 16 * 16, dtype=torch.float64, device=dev)
+    Xp[:T, :D] = Xd
+    Wp = torch.zeros(Tp, G + (G & 1), dtype=torch.float64, device=dev)
+    Wp[:T, :G] = Od
+    Jn = torch.zeros(G, ldj, ldj, dtype=torch.float64, device=dev)
+    call("pgl_weighted_gram", ptr(Xp), Xp.shape[1], Xp.shape[1], ptr(Wp), Wp.shape[1], Tp, D, G, ptr(Jn), ldj, ldj * ldj, 0, None)
+    torch.cuda.synchronize()
+    Jn = Jn.cpu().numpy()[:, :D, :D]
+    low = np.tril(np.ones((D, D), dtype=bool))
+    for g in range(G):
+        ref = np.asarray((Xl * Om[:, g].astype(np.longdouble)[:, None]).T @ Xl, dtype=np.longdouble)
+        na = np.sqrt((X * X).sum(0))
+        nb = np.sqrt(((Om[:, g:g + 1] * X) ** 2).sum(0))
+        den = np.maximum(np.outer(na, nb), 1e-300)
+        e_int = float(np.max((np.abs(Ji[g] - ref) / den)[low]))
+        e_f64 = float(np.max((np.abs(Jn[g] - ref) / den)[low]))
+        assert e_int < 5e-15 and e_int < 20 * max(e_f64, 2e-16), (e_int, e_f64)
+    # accumulate flag (second data set)
+    call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 1, None)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(np.tril(J.cpu().numpy()[0, :D, :D]), 2 * np.tril(Ji[0]), rtol=1e-15)
