@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--B", type=int)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--gram", default="fp64", choices=["fp64", "int8"],
+                    help="likelihood Gram on the fp64 MFMA (default) or by exact integer arithmetic on the int8 MFMA (opt-in, DESIGN.md section 9)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("N", "T", "B"):
@@ -119,7 +121,10 @@ def main():
     np.random.seed(0)
     basis, Y = synth(N, B, T, L)
     t_setup = time.perf_counter()
-    ekw = dict(batch=args.batch) if args.batch else None
+    ekw = dict(batch=args.batch) if args.batch else {}
+    if args.gram != "fp64":
+        ekw["gram"] = args.gram
+    ekw = ekw or None
     if cfg.get("obs") == "negbin":
         Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)     # counts, mean 0.35
         model = NegativeBinomialGLM(N, basis=basis, regression_kwargs=dict(S_w=1.0, mu_b=-2.0, xi=2.0), seed=0, engine_kwargs=ekw)
@@ -181,6 +186,16 @@ def main():
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll,
         }
+        if args.gram == "int8":
+            # 15 int8 residue-plane products per neuron (T D (D+1) multiply-adds each, lower triangle) + conversion + CRT, timed together
+            # with HIP events as stage "gram"; peak: dense i8 MFMA ~5 POPS (2x the bf16 figure of MI355X_MICROARCH.md)
+            ops = 15.0 * g["work"]
+            ach = ops / (g["ms"] * 1e-3) * 1e-12 if g["ms"] > 0 else None
+            out["dtype"] = "i8 residues -> f64 (exact CRT of 50-bit fixed-point operands)"
+            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_32x32x32_i8, 15 residue planes) + CRT", "achieved": ach,
+                               "peak": 5000.0, "unit": "TOP/s", "frac": ach / 5000.0 if ach else None, "traffic": None,
+                               "launches": g["calls"], "avg_launch_ms": g["ms"] / g["calls"] if g["calls"] else None,
+                               "fp64_equivalent_tflops": achieved}
         if cfg.get("obs") == "gaussian":
             # no per-neuron Gram here: X'X is formed once in add_data and only scaled per sweep (HBM-bound streaming store)
             gs = stages.get("gram_scale", dict(ms=0.0, calls=0, work=0.0))

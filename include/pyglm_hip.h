@@ -90,7 +90,7 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
  * (A = rint(x 2^e), B = rint(omega x 2^f)): one int8 GEMM per modulus for 15 coprime moduli <= 255, int32 accumulation (T <= 131072),
  * exact Chinese-remainder reconstruction, J = S 2^-(e+f).  Error ~1e-15 |a_i||b_j|, the level of the fp64 product itself.
  *   pgl_i8_colmax   out[c] = max(out[c], max_t |V[t][c]|)   (out zero-filled by the caller; X columns once, omega columns per sweep)
- *   pgl_i8_planes   residue planes [G][15][Dq][Kp] (int8, time contiguous; Dq = D rounded up to 256, Kp = T rounded up to 64) of X
+ *   pgl_i8_planes   residue planes [G][15][Dq][Kp] (int8, time contiguous; Dq = D rounded up to 256, Kp = T rounded up to 64, at least 256) of X
  *                   (Om = NULL, G = 1) or of omega_g X for the G columns of Om; sizes from pgl_i8_plane_bytes
  *   pgl_i8_gram     J[g] (+)= X' diag(omega_g) X, lower triangle, for the G neurons of planes_wx; residues: scratch of
  *                   G * pgl_i8_residue_bytes(D) bytes */

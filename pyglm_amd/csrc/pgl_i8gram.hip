@@ -16,9 +16,30 @@
 namespace {
 
 constexpr int NP = 15;
-__constant__ int c_mod[NP] = {255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193};
-static const int h_mod[NP] = {255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193};
-__constant__ int c_inv[NP][NP];      // c_inv[j][i] = p_j^-1 mod p_i  (j < i)
+// compile-time table: every use below sits in a fully unrolled loop, so reductions mod p become multiply-shift sequences
+struct ModTable {
+    int p[NP] = {255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193};
+    int inv[NP][NP] = {};             // inv[j][i] = p_j^-1 mod p_i
+    int m17[NP] = {}, m34[NP] = {};   // 2^17 mod p, 2^34 mod p
+    constexpr ModTable() {
+        for (int j = 0; j < NP; ++j)
+            for (int i = 0; i < NP; ++i) {
+                if (i == j) continue;
+                const int a = p[j] % p[i];
+                int x = 1;
+                while ((a * x) % p[i] != 1) ++x;
+                inv[j][i] = x;
+            }
+        for (int i = 0; i < NP; ++i) {
+            long v = 1;
+            for (int k = 0; k < 17; ++k) v = (v * 2) % p[i];
+            m17[i] = (int)v;
+            m34[i] = (int)((v * v) % p[i]);
+        }
+    }
+};
+constexpr ModTable MT{};
+__constant__ int c_mod[NP] = {255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193};   // run-time indexed (Gram epilogue)
 constexpr int BETA = 50;             // bits of the scaled integer operands
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -59,17 +80,19 @@ struct PlaneArgs {
     int T, D, Dq; long Kp;
 };
 
-// tile = 256 time bins x 32 columns; the scaled integers go through LDS so that a lane ends up with 4 consecutive time bins of one
-// column and stores one packed dword per plane (256 contiguous bytes per wave)
+// tile = 256 time bins x 16 columns (33 KB of LDS: four workgroups per CU keep enough loads in flight); the scaled integers go through
+// LDS so that a lane ends up with 4 consecutive time bins of one column and stores one packed dword per plane (256 contiguous bytes
+// per wave)
+constexpr int PT_D = 16;
 __global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a) {
-    __shared__ double tile[32][257];
-    const int t0 = blockIdx.x * 256, d0 = blockIdx.y * 32, gz = blockIdx.z;
+    __shared__ double tile[PT_D][257];
+    const int t0 = blockIdx.x * 256, d0 = blockIdx.y * PT_D, gz = blockIdx.z;
     const int tid = threadIdx.x;
     {
-        const int dl = tid & 31, d = d0 + dl;
+        const int dl = tid & (PT_D - 1), d = d0 + dl;
         int e = 0;
         if (d < a.D) e = scale_exp(a.Om ? a.wmax[gz] * a.xmax[d] : a.xmax[d]);
-        for (int tl = tid >> 5; tl < 256; tl += 8) {
+        for (int tl = tid / PT_D; tl < 256; tl += 256 / PT_D) {
             const int t = t0 + tl;
             double v = 0.0;
             if (t < a.T && d < a.D) {
@@ -82,28 +105,43 @@ __global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a) {
     }
     __syncthreads();
     const int tg = tid & 63;
-    for (int dl = tid >> 6; dl < 32; dl += 4) {
+    if (t0 + 4 * tg >= a.Kp) return;
+    for (int dl = tid >> 6; dl < PT_D; dl += 4) {
         const int d = d0 + dl;
-        if (d >= a.Dq) break;
-        if (t0 + 4 * tg >= a.Kp) continue;
-        const double v0 = tile[dl][4 * tg], v1 = tile[dl][4 * tg + 1], v2 = tile[dl][4 * tg + 2], v3 = tile[dl][4 * tg + 3];
+        // the scaled integers as sign + three limbs |I| = a 2^34 + b 2^17 + c; residue = sign * ((a m34 + b m17 + c) mod p), folded to
+        // [-p/2, p/2] -- integer multiply-adds and a division by a compile-time constant per plane
+        int la[4], lb[4], lc[4], sg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double v = tile[dl][4 * tg + k];
+            const double av = fabs(v);
+            const double hi = floor(av * 0x1p-34);                 // exact: av is an integer < 2^50
+            sg[k] = v < 0.0 ? -1 : 1;
+            la[k] = (int)hi;
+            const double rem = av - hi * 0x1p34;                   // < 2^34, exact
+            const double mid = floor(rem * 0x1p-17);
+            lb[k] = (int)mid;
+            lc[k] = (int)(rem - mid * 0x1p17);
+        }
         int8_t* dst = a.P + (((long)gz * NP) * a.Dq + d) * a.Kp + t0 + 4 * tg;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const double p = (double)c_mod[q], ip = 1.0 / p;
-            auto res = [&](double v) {
-                double r = fma(-p, rint(v * ip), v);             // exact: |v| < 2^50, the quotient is an integer < 2^43
-                if (r > 0.5 * p) r -= p; else if (r < -0.5 * p) r += p;
-                return (int)r & 0xff;
-            };
-            const unsigned w = (unsigned)res(v0) | ((unsigned)res(v1) << 8) | ((unsigned)res(v2) << 16) | ((unsigned)res(v3) << 24);
+            const int p = MT.p[q];
+            unsigned w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int r = (la[k] * MT.m34[q] + lb[k] * MT.m17[q] + lc[k]) % p;          // < 2^16 * 255 + 2^17 * 255 + 2^17 < 2^26
+                if (r > p / 2) r -= p;
+                r *= sg[k];
+                w |= (unsigned)(r & 0xff) << (8 * k);
+            }
             *reinterpret_cast<unsigned*>(dst + (long)q * a.Dq * a.Kp) = w;
         }
     }
 }
 
 // ------------------------------------------------------------------ int8 Gram of the planes, reduced mod p
-constexpr int TM = 256, TN = 256, BKB = 64, NST = 3;
+constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
 constexpr int STAGE_BYTES = (TM + TN) * BKB;
 constexpr int GRAM_LDS = NST * STAGE_BYTES;
 
@@ -125,9 +163,10 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int ntm = g.Dq / TM;
     const int ntiles = ntm * (ntm + 1) / 2;
-    // item = (tile, neuron of the group, plane), plane fastest: neighbours share nothing but run the same tile of the same X rows
-    const int q = blockIdx.x % NP, gz = (blockIdx.x / NP) % g.G, tile = blockIdx.x / (NP * g.G);
-    if (tile >= ntiles) return;
+    // item = (neuron of the group, plane, tile), tile fastest: the workgroups resident together work on one plane pair and share its
+    // 256-row strips through L2 (plane-fastest order streamed every strip from HBM: 517 GB per launch, 5.3 TB/s, memory-bound)
+    const int tile = blockIdx.x % ntiles, q = (blockIdx.x / ntiles) % NP, gz = blockIdx.x / (ntiles * NP);
+    if (gz >= g.G) return;
     const int tm = isqrt_tri_i(tile), tn = tile - tm * (tm + 1) / 2;
     const int m0 = tm * TM, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,29 +207,48 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
         const int pc = (kk * 2 + fk) ^ ((row >> 2) & 3);
         return *reinterpret_cast<const v4i*>(lds + stage * STAGE_BYTES + row * BKB + pc * 16);
     };
-    dma(0);
-    if (nkt > 1) dma(1);
-    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // Pipeline: NST - 1 = 3 tiles requested ahead; fragments double-buffered in registers, every LDS read and DMA request issued in
+    // the shadow of an MFMA (order pinned with sched_barrier); the barrier sits in the MIDDLE of a K tile (after its first k-step):
+    // it publishes tile kt+1, whose first fragments are fetched during the second k-step, and frees the stage of tile kt-1 for the
+    // requests of tile kt+3.  Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
+    long gadv = BKB;                 // 0 once the last tile has been requested: the cursors stop and the last tile is requested again
+    auto dma_piece = [&](int stage, int i) {      // (into a stage nobody reads any more) -- no branch in front of a request
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
+        gp[i] += gadv;
+    };
+    for (int p = 0; p < NST - 1; ++p) if (p < nkt) dma(p);
+    if (nkt >= NST - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    v4i F[2][6];
+    auto rd = [&](int stage, int kk, int f) {
+        return f < 4 ? frag(stage, wm * 128 + f * 32 + fr, kk) : frag(stage, TM + wn * 64 + (f - 4) * 32 + fr, kk);
+    };
+#pragma unroll
+    for (int f = 0; f < 6; ++f) F[0][f] = rd(0, 0, f);
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int nxt = cur == NST - 1 ? 0 : cur + 1;
-        const int dst = nxt == NST - 1 ? 0 : nxt + 1;
-        if (kt + 2 < nkt) dma(dst);
+        const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes tile kt+NST-1
+        if (kt + NST >= nkt) gadv = 0;
+        // ---- first k-step (set 0): prefetch the fragments of this tile's second k-step
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            v4i a[4], b[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = frag(cur, wm * 128 + i * 32 + fr, kk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = frag(cur, TM + wn * 64 + j * 32 + fr, kk);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int m = 0; m < 8; ++m) {
+            acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0][m >> 1], F[0][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
+            if (m < 6) F[1][m] = rd(cur, 1, m);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- second k-step (set 1): prefetch the first fragments of tile kt+1, request tile kt+3
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[1][m >> 1], F[1][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
+            if (m < 6) F[0][m] = rd(nxt, 0, m);
+            if (m & 1) dma_piece(dst, m >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         cur = nxt;
     }
     // epilogue: reduce mod p (symmetric) and store bytes.  C/D layout of 32x32 i32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -229,19 +287,16 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
     // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...
 #pragma unroll
     for (int q = 1; q < NP; ++q) {
-        const int p = c_mod[q];
+        const int p = MT.p[q];
         int t = v[q];
 #pragma unroll
-        for (int r = 0; r < q; ++r) {
-            t = ((t - v[r]) % p) * c_inv[r][q] % p;              // |.| < 2^17: no overflow
-        }
-        t %= p;
+        for (int r = 0; r < q; ++r) t = ((t - v[r]) % p) * MT.inv[r][q] % p;          // |.| < 2^17: no overflow
         if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
         v[q] = t;
     }
     double s = (double)v[NP - 1];
 #pragma unroll
-    for (int q = NP - 2; q >= 0; --q) s = s * (double)c_mod[q] + (double)v[q];
+    for (int q = NP - 2; q >= 0; --q) s = s * (double)MT.p[q] + (double)v[q];
     const int e = scale_exp(a.xmax[i]) + scale_exp(a.wmax[gz] * a.xmax[j]);
     const double val = ldexp(s, -e);
     double* dst = a.J + (long)gz * a.strideJ + (long)i * a.ldj + j;
@@ -251,25 +306,11 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------ host side
-static int upload_tables() {
-    static bool done = false;
-    if (done) return PGL_OK;
-    int inv[15][15] = {};
-    for (int j = 0; j < 15; ++j)
-        for (int i = 0; i < 15; ++i) {
-            if (i == j) continue;
-            const int p = h_mod[i], a = h_mod[j] % p;
-            int x = 1;
-            for (; x < p; ++x) if ((a * x) % p == 1) break;
-            inv[j][i] = x;
-        }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_inv), inv, sizeof(inv)) != hipSuccess) { pgl_set_error("i8 gram: constant upload failed"); return PGL_ERR_HIP; }
-    done = true;
-    return PGL_OK;
-}
+// time bins per plane row: a multiple of the 64-byte K tile, at least four tiles (the Gram pipeline keeps three requested ahead)
+static long pgl_i8_kp(int T) { const long k = ((long)T + 63) / 64 * 64; return k < 256 ? 256 : k; }
 
 size_t pgl_k_i8_plane_bytes(int D, int T) {
-    const long Dq = (D + 255) / 256 * 256, Kp = (T + 63) / 64 * 64;
+    const long Dq = (D + 255) / 256 * 256, Kp = pgl_i8_kp(T);
     return (size_t)15 * Dq * Kp;
 }
 size_t pgl_k_i8_residue_bytes(int D) {
@@ -287,23 +328,19 @@ int pgl_k_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, hip
 // residue planes of X (Om == null, G = 1) or of omega_g X for the G weight columns Om[:, 0..G)
 int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* xmax, const double* wmax, int8_t* P, int T, int D, int G,
                     hipStream_t st) {
-    int rc = upload_tables();
-    if (rc) return rc;
     const int Dq = (D + 255) / 256 * 256;
-    const long Kp = (T + 63) / 64 * 64;
+    const long Kp = pgl_i8_kp(T);
     PlaneArgs a{X, ldx, Om, ldo, xmax, wmax, P, T, D, Dq, Kp};
-    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + 255) / 256), Dq / 32, G), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D, G), dim3(256), 0, st, a);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
 
 int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, const double* xmax, const double* wmax, double* J, long ldj, long strideJ,
                   int T, int D, int G, int accumulate, hipStream_t st) {
-    int rc = upload_tables();
-    if (rc) return rc;
     if (T > 131072) { pgl_set_error("i8 gram: T = %d > 131072 would overflow the int32 accumulators", T); return PGL_ERR_ARG; }
     const int Dq = (D + 255) / 256 * 256;
-    const long Kp = (T + 63) / 64 * 64;
+    const long Kp = pgl_i8_kp(T);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(i8_gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GRAM_LDS);

@@ -121,3 +121,39 @@ def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G):
     call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 1, None)
     torch.cuda.synchronize()
     np.testing.assert_allclose(np.tril(J.cpu().numpy()[0, :D, :D]), 2 * np.tril(Ji[0]), rtol=1e-15)
+
+
+@pytest.mark.parametrize("N,B,T,batch", [(60, 3, 1500, 16), (110, 4, 2500, None)])
+def test_sweep_with_integer_gram_equals_fp64_sweep_and_oracle(N, B, T, batch):
+    """a full engine sweep with gram='int8' against the default fp64 Gram (same decisions, weights to 1e-9) and against the oracle"""
+    from oracle import pyglm_oracle as orc
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    from tests.test_gpu_parity import _random_problem
+    basis, X, Y, rng = _random_problem(N, B, T, seed=N + 1)
+    kw = dict(rho=0.5, S_w=4.0, mu_w=0.0, mu_b=-1.5, S_b=2.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * a[:, :, None]
+    b = rng.standard_normal(N) - 1.5
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    hyp = prior_terms(np.array([r.S_w for r in regs]), np.array([r.mu_w for r in regs]), np.array([r.S_b[0, 0] for r in regs]),
+                      np.array([r.mu_b[0] for r in regs]))
+    rho = np.array([r.rho for r in regs])
+    perm, u, z = make_draws(41, 3, range(N), N, N * B)
+    outs, Js = [], []
+    for gram in ("int8", "fp64"):
+        eng = GibbsEngine(N, B, batch=batch, gram=gram)
+        eng.add_data(Y[: T // 2], X=X[: T // 2])
+        eng.add_data(Y[T // 2:], X=X[T // 2:])                  # two data sets: the second Gram accumulates
+        outs.append(eng.sweep(a, W, b, rho, *hyp, perm, u, z, seed=41, sweep=3)[:3])
+        Js.append(eng.posterior(0))
+    np.testing.assert_allclose(Js[0][0], Js[1][0], rtol=0, atol=1e-13 * np.abs(Js[1][0]).max())
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-9, atol=1e-11)
+    omegas = [eng.datasets[k].OK[: eng.datasets[k].T, :N].cpu().numpy() for k in range(2)]
+    for n in (0, N // 2, N - 1):
+        r = orc.Regression(N, B, **kw)
+        r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+        r.resample([(X[: T // 2], Y[: T // 2, n]), (X[T // 2:], Y[T // 2:, n])], [omegas[0][:, n], omegas[1][:, n]], perm[n], u[n], z[n])
+        np.testing.assert_array_equal(outs[0][0][n], r.a)
+        np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)

@@ -17,7 +17,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-constexpr int TM = 256, TN = 256, BKB = 64, NST = 3;
+constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
 constexpr int STAGE_BYTES = (TM + TN) * BKB;          // 32 KiB
 constexpr int LDS_BYTES = NST * STAGE_BYTES;
 
@@ -84,30 +84,48 @@ __global__ __launch_bounds__(512) void i8gram_kernel(Args g) {
         return *reinterpret_cast<const v4i*>(lds + stage * STAGE_BYTES + row * BKB + pc * 16);
     };
 
-    dma(0);
-    if (nkt > 1) dma(1);
-    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // Pipeline: NST - 1 = 3 tiles requested ahead; fragments double-buffered in registers, every LDS read and DMA request issued in
+    // the shadow of an MFMA (order pinned with sched_barrier); the barrier sits in the MIDDLE of a K tile (after its first k-step):
+    // it publishes tile kt+1, whose first fragments are fetched during the second k-step, and frees the stage of tile kt-1 for the
+    // requests of tile kt+3.  Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
+    long gadv = BKB;                 // 0 once the last tile has been requested: the cursors stop and the last tile is requested again
+    auto dma_piece = [&](int stage, int i) {      // (into a stage nobody reads any more) -- no branch in front of a request
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
+        gp[i] += gadv;
+    };
+    for (int p = 0; p < NST - 1; ++p) if (p < nkt) dma(p);
+    if (nkt >= NST - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    v4i F[2][6];
+    auto rd = [&](int stage, int kk, int f) {
+        return f < 4 ? frag(stage, wm * 128 + f * 32 + fr, kk) : frag(stage, TM + wn * 64 + (f - 4) * 32 + fr, kk);
+    };
+#pragma unroll
+    for (int f = 0; f < 6; ++f) F[0][f] = rd(0, 0, f);
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int nxt = cur == NST - 1 ? 0 : cur + 1;
-        const int dst = nxt == NST - 1 ? 0 : nxt + 1;
-        if (kt + 2 < nkt) dma(dst);
+        const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes tile kt+NST-1
+        if (kt + NST >= nkt) gadv = 0;
+        // ---- first k-step (set 0): prefetch the fragments of this tile's second k-step
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            v4i a[4], b[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = frag(cur, wm * 128 + i * 32 + fr, kk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = frag(cur, TM + wn * 64 + j * 32 + fr, kk);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int m = 0; m < 8; ++m) {
+            acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0][m >> 1], F[0][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
+            if (m < 6) F[1][m] = rd(cur, 1, m);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // tile kt+1 must have landed (requested one tile ago); this tile's 4 requests may stay in flight
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- second k-step (set 1): prefetch the first fragments of tile kt+1, request tile kt+3
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[1][m >> 1], F[1][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
+            if (m < 6) F[0][m] = rd(nxt, 0, m);
+            if (m & 1) dma_piece(dst, m >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         cur = nxt;
     }
     // epilogue: C/D layout of 32x32 i32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
