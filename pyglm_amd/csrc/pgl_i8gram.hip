@@ -80,62 +80,60 @@ struct PlaneArgs {
     int T, D, Dq; long Kp;
 };
 
-// tile = 256 time bins x 16 columns (33 KB of LDS: four workgroups per CU keep enough loads in flight); the scaled integers go through
-// LDS so that a lane ends up with 4 consecutive time bins of one column and stores one packed dword per plane (256 contiguous bytes
-// per wave)
+// tile = 256 time bins x 16 columns of X in LDS (33 KB: four workgroups per CU keep enough loads in flight), read ONCE and converted for
+// all G neurons of the group; a lane owns 4 consecutive time bins of one column and stores one packed dword per plane (256
+// contiguous bytes per wave and plane row)
 constexpr int PT_D = 16;
-__global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a) {
+__global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a, int G) {
     __shared__ double tile[PT_D][257];
-    const int t0 = blockIdx.x * 256, d0 = blockIdx.y * PT_D, gz = blockIdx.z;
+    const int t0 = blockIdx.x * 256, d0 = blockIdx.y * PT_D;
     const int tid = threadIdx.x;
     {
         const int dl = tid & (PT_D - 1), d = d0 + dl;
-        int e = 0;
-        if (d < a.D) e = scale_exp(a.Om ? a.wmax[gz] * a.xmax[d] : a.xmax[d]);
         for (int tl = tid / PT_D; tl < 256; tl += 256 / PT_D) {
             const int t = t0 + tl;
-            double v = 0.0;
-            if (t < a.T && d < a.D) {
-                v = a.X[(long)t * a.ldx + d];
-                if (a.Om) v *= a.Om[(long)t * a.ldo + gz];
-                v = rint(ldexp(v, e));
-            }
-            tile[dl][tl] = v;
+            tile[dl][tl] = (t < a.T && d < a.D) ? a.X[(long)t * a.ldx + d] : 0.0;
         }
     }
     __syncthreads();
-    const int tg = tid & 63;
-    if (t0 + 4 * tg >= a.Kp) return;
-    for (int dl = tid >> 6; dl < PT_D; dl += 4) {
-        const int d = d0 + dl;
-        // the scaled integers as sign + three limbs |I| = a 2^34 + b 2^17 + c; residue = sign * ((a m34 + b m17 + c) mod p), folded to
-        // [-p/2, p/2] -- integer multiply-adds and a division by a compile-time constant per plane
-        int la[4], lb[4], lc[4], sg[4];
+    const int tg = tid & 63, tb = t0 + 4 * tg;
+    if (tb >= a.Kp) return;
+    for (int gz = 0; gz < G; ++gz) {
+        double om[4] = {1.0, 1.0, 1.0, 1.0};
+        if (a.Om) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double v = tile[dl][4 * tg + k];
-            const double av = fabs(v);
-            const double hi = floor(av * 0x1p-34);                 // exact: av is an integer < 2^50
-            sg[k] = v < 0.0 ? -1 : 1;
-            la[k] = (int)hi;
-            const double rem = av - hi * 0x1p34;                   // < 2^34, exact
-            const double mid = floor(rem * 0x1p-17);
-            lb[k] = (int)mid;
-            lc[k] = (int)(rem - mid * 0x1p17);
+            for (int k = 0; k < 4; ++k) om[k] = tb + k < a.T ? a.Om[(long)(tb + k) * a.ldo + gz] : 0.0;
         }
-        int8_t* dst = a.P + (((long)gz * NP) * a.Dq + d) * a.Kp + t0 + 4 * tg;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int p = MT.p[q];
-            unsigned w = 0;
+        for (int dl = tid >> 6; dl < PT_D; dl += 4) {
+            const int d = d0 + dl;
+            const double scale = d < a.D ? ldexp(1.0, scale_exp(a.Om ? a.wmax[gz] * a.xmax[d] : a.xmax[d])) : 0.0;
+            // the scaled integers as sign + three limbs |I| = a 2^34 + b 2^17 + c; residue = sign * ((a m34 + b m17 + c) mod p), folded
+            // to [-p/2, p/2] -- integer multiply-adds and a division by a compile-time constant per plane
+            int la[4], lb[4], lc[4], sg[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                int r = (la[k] * MT.m34[q] + lb[k] * MT.m17[q] + lc[k]) % p;          // < 2^16 * 255 + 2^17 * 255 + 2^17 < 2^26
-                if (r > p / 2) r -= p;
-                r *= sg[k];
-                w |= (unsigned)(r & 0xff) << (8 * k);
+                const double v = rint(tile[dl][4 * tg + k] * om[k] * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
+                const double av = fabs(v);
+                const double hi = floor(av * 0x1p-34);                             // exact: av is an integer < 2^50
+                const double rem = av - hi * 0x1p34;
+                const double mid = floor(rem * 0x1p-17);
+                sg[k] = v < 0.0 ? -1 : 1;
+                la[k] = (int)hi; lb[k] = (int)mid; lc[k] = (int)(rem - mid * 0x1p17);
             }
-            *reinterpret_cast<unsigned*>(dst + (long)q * a.Dq * a.Kp) = w;
+            int8_t* dst = a.P + (((long)gz * NP) * a.Dq + d) * a.Kp + tb;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int p = MT.p[q];
+                unsigned w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int r = (la[k] * MT.m34[q] + lb[k] * MT.m17[q] + lc[k]) % p;      // < 2^16 * 255 + 2^17 * 255 + 2^17 < 2^26
+                    if (r > p / 2) r -= p;
+                    r *= sg[k];
+                    w |= (unsigned)(r & 0xff) << (8 * k);
+                }
+                *reinterpret_cast<unsigned*>(dst + (long)q * a.Dq * a.Kp) = w;
+            }
         }
     }
 }
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
         const int p = MT.p[q];
         int t = v[q];
 #pragma unroll
-        for (int r = 0; r < q; ++r) t = ((t - v[r]) % p) * MT.inv[r][q] % p;          // |.| < 2^17: no overflow
+        for (int r = 0; r < q; ++r) t = (t - v[r]) * MT.inv[r][q] % p;                // |t - v| < 2^9, inverse < 2^8: no overflow
         if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
         v[q] = t;
     }
@@ -331,7 +329,7 @@ int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const
     const int Dq = (D + 255) / 256 * 256;
     const long Kp = pgl_i8_kp(T);
     PlaneArgs a{X, ldx, Om, ldo, xmax, wmax, P, T, D, Dq, Kp};
-    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D, G), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
