@@ -110,7 +110,7 @@ class GibbsEngine(object):
         per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
         if batch is None:
             free, _ = torch.cuda.mem_get_info(self.dev)
-            budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * (0.45 if self.gram == "fp64" else 0.30))
+            budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * 0.45)
             batch = max(2, min(self.nloc, budget // per_neuron))
         self.nb = int(min(batch, self.nloc))
         self.design_only = design_only
