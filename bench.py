@@ -24,6 +24,7 @@ CONFIGS = {   # BASELINE.json configs
     "cfg3g": dict(N=1024, B=5, T=100000, L=100, obs="gaussian"),  # not in BASELINE.json: SparseGaussianGLM at the cfg3 shape
 }
 PEAK_HBM_GBS = 8000.0
+PEAK_I8_MFMA_TOPS = 5000.0
 PEAK_F64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 64 cyc (tools/ubench2_f64.hip, measured)
 
 
@@ -87,8 +88,11 @@ def main():
     ap.add_argument("--B", type=int)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--gram", default="fp64", choices=["fp64", "int8"],
-                    help="likelihood Gram on the fp64 MFMA (default) or by exact integer arithmetic on the int8 MFMA (opt-in, DESIGN.md section 9)")
+    ap.add_argument("--gram", default="auto", choices=["auto", "fp64", "int8"],
+                    help="likelihood Gram: auto (the engine's default: exact integer arithmetic on the int8 MFMA where that is faster, DESIGN.md "
+                         "section 8c), or forced onto the fp64 MFMA kernel / the int8 path")
+    ap.add_argument("--no-fp64-compare", action="store_true",
+                    help="skip the extra (untimed for `value`) sweep with the fp64-MFMA Gram that fills the fp64_gram_path object")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("N", "T", "B"):
@@ -122,7 +126,7 @@ def main():
     basis, Y = synth(N, B, T, L)
     t_setup = time.perf_counter()
     ekw = dict(batch=args.batch) if args.batch else {}
-    if args.gram != "fp64":
+    if args.gram != "auto":
         ekw["gram"] = args.gram
     ekw = ekw or None
     if cfg.get("obs") == "negbin":
@@ -160,6 +164,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ll = model.log_likelihood()
+    # the same sampler with the Gram forced onto the fp64-MFMA kernel, one more sweep of the same chain (not part of `value`)
+    cmp64 = None
+    if any(ds.int8 for ds in model.engine.datasets) and not args.no_fp64_compare:
+        for ds in model.engine.datasets:
+            ds.int8 = False
+        model.engine.profile = True
+        model.engine.collect_timings()
+        barrier()
+        t1 = time.perf_counter()
+        model.resample_model()
+        barrier()
+        dt64 = time.perf_counter() - t1
+        st64 = model.engine.collect_timings()
+        model.engine.profile = False
+        if use_dist:
+            t = torch.tensor([dt64], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt64 = float(t.item())
+        g64 = st64.get("gram", dict(ms=0.0, calls=0, work=0.0))
+        a64 = (g64["work"] / (g64["ms"] * 1e-3) * 1e-12) if g64["ms"] > 0 else None
+        cmp64 = {"value": 1.0 / dt64, "unit": "sweeps/s", "ms_per_step": dt64 * 1e3, "steps": 1,
+                 "note": "one further sweep of the same chain with the Gram on the fp64-MFMA kernel (engine gram='fp64')",
+                 "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": a64,
+                              "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (a64 / PEAK_F64_MFMA_TFLOPS) if a64 else None,
+                              "launches": g64["calls"], "avg_launch_ms": (g64["ms"] / g64["calls"]) if g64["calls"] else None}}
 
     if rank == 0:
         g = stages.get("gram", dict(ms=0.0, calls=0, work=0.0))
@@ -168,7 +197,8 @@ def main():
         # workload and launch geometry they were collected on (cfg3, one GPU)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "gram_pmc.json")
-        if os.path.exists(pmc) and args.config == "cfg3" and world == 1 and (N, B, T) == (1024, 5, 100000):
+        pmc_ok = os.path.exists(pmc) and args.config == "cfg3" and world == 1 and (N, B, T) == (1024, 5, 100000)
+        if pmc_ok:
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -186,16 +216,27 @@ def main():
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll,
         }
-        if args.gram == "int8":
-            # 15 int8 residue-plane products per neuron (T D (D+1) multiply-adds each, lower triangle) + conversion + CRT, timed together
-            # with HIP events as stage "gram"; peak: dense i8 MFMA ~5 POPS (2x the bf16 figure of MI355X_MICROARCH.md)
-            ops = 15.0 * g["work"]
-            ach = ops / (g["ms"] * 1e-3) * 1e-12 if g["ms"] > 0 else None
-            out["dtype"] = "i8 residues -> f64 (exact CRT of 50-bit fixed-point operands)"
-            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_32x32x32_i8, 15 residue planes) + CRT", "achieved": ach,
-                               "peak": 5000.0, "unit": "TOP/s", "frac": ach / 5000.0 if ach else None, "traffic": None,
-                               "launches": g["calls"], "avg_launch_ms": g["ms"] / g["calls"] if g["calls"] else None,
-                               "fp64_equivalent_tflops": achieved}
+        gi = stages.get("gram.int8")
+        if gi and gi["ms"] > g["ms"]:
+            # the Gram went through the integer matrix cores: 15 int8 residue-plane products per neuron, T D (D+1) operations each (lower
+            # triangle, 2 per multiply-add); HIP events around i8_gram_kernel alone (conversion = stage gram.planes, CRT = gram.crt).
+            # peak: dense i8 MFMA 5 POP/s (2x the bf16 figure of MI355X_MICROARCH.md; 4.92 measured at 2.39 GHz with constant operands;
+            # with random operand bytes the package power limit holds the bare MFMA loop to 3.45 POP/s at 1.77 GHz: tools/ubench_i8.hip)
+            ach = 15.0 * gi["work"] / (gi["ms"] * 1e-3) * 1e-12
+            tr = None
+            if pmc_ok:
+                try:
+                    tr = json.load(open(pmc)).get("int8", {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    tr = None
+            out["dtype"] = "f64 (likelihood Gram: exact integer arithmetic on i8 residue planes, CRT back to f64)"
+            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_32x32x32_i8; 15 residue planes of 4 neurons per launch)",
+                               "achieved": ach, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS, "traffic": tr,
+                               "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"],
+                               "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,
+                               "power_limited_mfma_only_tops": 3450.0}
+            if cmp64:
+                out["fp64_gram_path"] = cmp64
         if cfg.get("obs") == "gaussian":
             # no per-neuron Gram here: X'X is formed once in add_data and only scaled per sweep (HBM-bound streaming store)
             gs = stages.get("gram_scale", dict(ms=0.0, calls=0, work=0.0))

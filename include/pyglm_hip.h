@@ -85,22 +85,26 @@ int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long
 int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* border_omega, const double* border_kappa, long ldb, const double* Jw,
                            const double* hw, const int* label, const double* Jb, const double* hb, int nb, int N, int B, void* hip_stream);
 
-/* ---- the same weighted Gram on the INTEGER matrix cores (opt-in) -------------------------------
- * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to 50-bit fixed point
- * (A = rint(x 2^e), B = rint(omega x 2^f)): one int8 GEMM per modulus for 15 coprime moduli <= 255, int32 accumulation (T <= 131072),
- * exact Chinese-remainder reconstruction, J = S 2^-(e+f).  Error ~1e-15 |a_i||b_j|, the level of the fp64 product itself.
+/* ---- the same weighted Gram on the INTEGER matrix cores -------------------------------------------
+ * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to beta-bit fixed point
+ * (A = rint(x 2^e), B = rint(omega x 2^f); beta = 50 for T <= 112 000 time bins, the largest value with T 2^(2 beta) < prod(p)/2 beyond):
+ * one int8 GEMM per modulus for 15 pairwise coprime moduli <= 256, int32 accumulation (re-reduced every 128 000 bins), exact
+ * Chinese-remainder reconstruction, J = S 2^-(e+f).  Error ~1e-15 |a_i||b_j|, the level of the fp64 product itself.
  *   pgl_i8_colmax   out[c] = max(out[c], max_t |V[t][c]|)   (out zero-filled by the caller; X columns once, omega columns per sweep)
- *   pgl_i8_planes   residue planes [G][15][Dq][Kp] (int8, time contiguous; Dq = D rounded up to 256, Kp = T rounded up to 64, at least 256) of X
- *                   (Om = NULL, G = 1) or of omega_g X for the G columns of Om; sizes from pgl_i8_plane_bytes
- *   pgl_i8_gram     J[g] (+)= X' diag(omega_g) X, lower triangle, for the G neurons of planes_wx; residues: scratch of
- *                   G * pgl_i8_residue_bytes(D) bytes */
+ *   pgl_i8_planes   residue planes [G][15] of Dq * Kp signed bytes each (Dq = D rounded up to 256, Kp = T rounded up to 64, at least 256),
+ *                   BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024 +
+ *                   (r % 16) 64; of X (Om = NULL, G = 1) or of omega_g X for the G columns of Om; sizes from pgl_i8_plane_bytes
+ *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower 256 x 256 tiles, [G][15][Dq][Dq] signed bytes
+ *                   (G * pgl_i8_residue_bytes(D))
+ *   pgl_i8_crt      J[g] (+)= X' diag(omega_g) X, lower triangle, from the residues */
 size_t pgl_i8_plane_bytes(int D, int T);
 size_t pgl_i8_residue_bytes(int D);
 int pgl_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, void* hip_stream);
 int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* xmax, const double* wmax, void* planes, int T, int D, int G,
                   void* hip_stream);
-int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ,
-                int T, int D, int G, int accumulate, void* hip_stream);
+int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, void* hip_stream);
+int pgl_i8_crt(const void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ, int T, int D, int G, int accumulate,
+               void* hip_stream);
 
 /* ---- collapsed adjacency resampling (pyglm/regression.py:282-320 + 343-378) ------------------------------------ */
 typedef struct {

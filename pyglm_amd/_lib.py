@@ -40,7 +40,8 @@ SIGNATURES = {
     "pgl_i8_residue_bytes": [c_i],
     "pgl_i8_colmax": [c_p, c_l, c_i, c_i, c_p, c_p],
     "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "pgl_i8_gram": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
     "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "pgl_flip_kmax": [],

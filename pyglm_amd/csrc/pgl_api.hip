@@ -29,7 +29,8 @@ size_t pgl_k_i8_plane_bytes(int, int);
 size_t pgl_k_i8_residue_bytes(int);
 int pgl_k_i8_colmax(const double*, long, int, int, double*, hipStream_t);
 int pgl_k_i8_planes(const double*, long, const double*, long, const double*, const double*, int8_t*, int, int, int, hipStream_t);
-int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
+int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, int, int, int, hipStream_t);
+int pgl_k_i8_crt(const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
 struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
@@ -156,11 +157,14 @@ int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const d
     PGL_CHECK_ARG(Om != nullptr || G == 1);
     return pgl_k_i8_planes(X, ldx, Om, ldo, xmax, wmax, static_cast<int8_t*>(planes), T, D, G, ST(st));
 }
-int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ,
-                int T, int D, int G, int accumulate, void* st) {
-    PGL_CHECK_ARG(planes_x && planes_wx && residues && xmax && wmax && J && T > 0 && D > 0 && G > 0 && ldj >= D);
-    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), xmax, wmax, J, ldj,
-                         strideJ, T, D, G, accumulate, ST(st));
+int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, void* st) {
+    PGL_CHECK_ARG(planes_x && planes_wx && residues && T > 0 && D > 0 && G > 0);
+    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), T, D, G, ST(st));
+}
+int pgl_i8_crt(const void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ, int T, int D, int G, int accumulate,
+               void* st) {
+    PGL_CHECK_ARG(residues && xmax && wmax && J && T > 0 && D > 0 && G > 0 && ldj >= D);
+    return pgl_k_i8_crt(static_cast<const int8_t*>(residues), xmax, wmax, J, ldj, strideJ, T, D, G, accumulate, ST(st));
 }
 
 static PglFlipState to_state(const pgl_flip_t* s) {

@@ -49,3 +49,5 @@ struct PglGemmArgs {
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
+// 8 zeroed per-XCD work counters for one persistent launch on stream st (a ring of slots owned by the library; pgl_gemm.hip)
+int* pgl_sched_slot(hipStream_t st);

@@ -794,6 +794,9 @@ static int launch_gram_fine(const PglGemmArgs& a0, hipStream_t st) {
 
 }  // namespace
 
+int* pgl_sched_slot(hipStream_t st) { return sched_slot(st); }
+
+
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
     PGL_CHECK_ARG(a.K % BK == 0 && a.M > 0 && a.N > 0 && a.nbatch > 0);
     PGL_CHECK_ARG(a.a_cols % 2 == 0 && a.b_cols % 2 == 0 && a.lda % 2 == 0 && a.ldb % 2 == 0);

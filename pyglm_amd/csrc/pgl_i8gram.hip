@@ -1,26 +1,30 @@
 // The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (an OPT-IN alternative to the fp64
-// kernel of pgl_gemm.hip).  The fp64 operands are scaled column by column to 50-bit integers,
+// kernel of pgl_gemm.hip).  The fp64 operands are scaled column by column to beta-bit integers (beta = 50 up to
+// T = 112 000 time bins, 49 beyond),
 //     A[t][i] = rint(x_ti 2^eA_i),      B_n[t][j] = rint(omega_nt x_tj 2^fB_nj),
-// the integer Gram S = A'B_n is computed modulo 15 pairwise coprime moduli p <= 255 -- one int8 GEMM per modulus on residues in
-// [-p/2, p/2], int32 accumulation (exact for K <= 131072) -- and reconstructed exactly by the Chinese remainder theorem
-// (|S| <= K 2^100 < prod(p)/2 = 2^116.6);  J = S 2^-(eA_i + fB_nj).  The only approximation is the rounding of the operands to
-// 50-bit fixed point per column: error ~1e-15 |a_i||b_j|, the level of an fp64 product at K = 1e5 (tools/ozaki2_accuracy.py).
+// the integer Gram S = A'B_n is computed modulo 15 pairwise coprime moduli p <= 256 -- one int8 GEMM per modulus on residues that fit
+// a signed byte, int32 accumulation (re-reduced mod p every 128 000 time bins) -- and reconstructed exactly by the Chinese remainder
+// theorem (|S| <= T 2^(2 beta) < prod(p)/2 = 2^116.78);  J = S 2^-(eA_i + fB_nj).  The only approximation is the rounding of the operands
+// to beta-bit fixed point per column: error ~1e-15 |a_i||b_j|, the level of an fp64 product at K = 1e5 (tools/ozaki2_accuracy.py).
 //
-//   i8_planes_kernel   fp64 (t-major) -> 15 residue planes, K (time) contiguous:  PA[q][d][t] for X (once per data set),
-//                      PB[g][q][d][t] for omega_g X (per neuron, per sweep); one pass over X per neuron
+//   i8_planes_kernel   fp64 (t-major) -> 15 residue planes in BLOCKED layout [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once
+//                      per data set), PB[g] for omega_g X (per neuron, per sweep); one pass over X per group of neurons; residues by four
+//                      fp64 operations each (no integer division)
 //   i8_gram_kernel     R[g][q] = (PA[q] PB[g][q]') mod p_q on lower 256 x 256 tiles (v_mfma_i32_32x32x32_i8; 8 waves = 2 x 4, wave tile
-//                      128 x 64; 64-byte K tiles DMA-staged into 3 LDS stages, 16-byte chunks XOR-swizzled: conflict-free ds_read_b128)
+//                      128 x 64; K tiles DMA-staged into 4 LDS stages, one contiguous KiB per request, 16-byte chunks XOR-swizzled:
+//                      conflict-free ds_read_b128); persistent workgroups, per-XCD work lists in a clustered tile order (L2 sharing)
 //   i8_crt_kernel      15 residues -> mixed-radix digits (Garner) -> fp64 by Horner -> scaled into the lower triangle of J
 #include "pgl_common.h"
+#include <cmath>
 
 namespace {
 
 constexpr int NP = 15;
-// compile-time table: every use below sits in a fully unrolled loop, so reductions mod p become multiply-shift sequences
+// compile-time table: every use below sits in a fully unrolled loop, so reductions mod p become multiply-shift sequences.
+// 256 comes first: its residue is the low byte, and as the least significant mixed-radix digit its two representations of 128 are harmless
 struct ModTable {
-    int p[NP] = {255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193};
+    int p[NP] = {256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197};
     int inv[NP][NP] = {};             // inv[j][i] = p_j^-1 mod p_i
-    int m17[NP] = {}, m34[NP] = {};   // 2^17 mod p, 2^34 mod p
     constexpr ModTable() {
         for (int j = 0; j < NP; ++j)
             for (int i = 0; i < NP; ++i) {
@@ -30,28 +34,21 @@ struct ModTable {
                 while ((a * x) % p[i] != 1) ++x;
                 inv[j][i] = x;
             }
-        for (int i = 0; i < NP; ++i) {
-            long v = 1;
-            for (int k = 0; k < 17; ++k) v = (v * 2) % p[i];
-            m17[i] = (int)v;
-            m34[i] = (int)((v * v) % p[i]);
-        }
     }
 };
 constexpr ModTable MT{};
-__constant__ int c_mod[NP] = {255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193};   // run-time indexed (Gram epilogue)
-constexpr int BETA = 50;             // bits of the scaled integer operands
+__constant__ int c_mod[NP] = {256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197};   // run-time indexed (Gram epilogue)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__device__ __forceinline__ int scale_exp(double maxabs) {       // e with |v 2^e| < 2^BETA for every |v| <= maxabs
+__device__ __forceinline__ int scale_exp(double maxabs, int beta) {       // e with |v 2^e| < 2^beta for every |v| <= maxabs
     if (!(maxabs > 0.0)) return 0;
     int ex;
     (void)frexp(maxabs, &ex);                                    // maxabs = m 2^ex, m in [0.5, 1)
-    return BETA - ex;
+    return beta - ex;
 }
 
 // ------------------------------------------------------------------ column maxima of |X| (per data set) and of omega (per neuron)
@@ -76,64 +73,73 @@ struct PlaneArgs {
     const double* Om; long ldo;           // [T][ldo] weights of the group's neurons (null: unweighted, one "neuron")
     const double* xmax;                   // [D]
     const double* wmax;                   // [G] (weighted only)
-    int8_t* P;                            // [G][NP][Dq][Kp]
-    int T, D, Dq; long Kp;
+    int8_t* P;                            // [G][NP] planes of Dq * Kp bytes, blocked [Dq / 16][Kp / 64][16][64]
+    int T, D, Dq; long Kp; int beta;
 };
 
-// tile = 256 time bins x 16 columns of X in LDS (33 KB: four workgroups per CU keep enough loads in flight), read ONCE and converted for
-// all G neurons of the group; a lane owns 4 consecutive time bins of one column and stores one packed dword per plane (256
-// contiguous bytes per wave and plane row)
-constexpr int PT_D = 16;
+// A workgroup converts 256 time bins x 16 columns (one row block, four K tiles) of X, staged ONCE in LDS, for all G neurons of the group.
+// Wave w owns K tile w: lane l -> column l / 4, 16 consecutive time bins (one 16-byte chunk of the 64-byte row), so a wave stores one
+// contiguous KiB -- exactly one request of the Gram kernel -- per plane.  Residue of the integer v (|v| < 2^50, carried as fp64) mod p:
+//     q = rint(v / p) by the add-and-subtract of M = 1.5 2^52,     r = v - p q  (one fma, exact),
+// |r| <= p/2 + 0.4 < 128: a valid signed-byte representative (not always the smallest one; the GEMM and the CRT only need congruence).
+// The fma is taken on v + M, so the byte is the low byte of the result's mantissa: no conversion instruction, no integer division.
+constexpr int PT_D = 16, PT_T = 256;
+constexpr double MAGIC = 6755399441055744.0;      // 1.5 * 2^52
 __global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a, int G) {
-    __shared__ double tile[PT_D][257];
-    const int t0 = blockIdx.x * 256, d0 = blockIdx.y * PT_D;
+    __shared__ double tile[PT_D][PT_T + 1];
+    __shared__ double oms[PT_T];
+    const int t0 = blockIdx.x * PT_T, d0 = blockIdx.y * PT_D;
     const int tid = threadIdx.x;
     {
         const int dl = tid & (PT_D - 1), d = d0 + dl;
-        for (int tl = tid / PT_D; tl < 256; tl += 256 / PT_D) {
+        for (int tl = tid / PT_D; tl < PT_T; tl += 256 / PT_D) {
             const int t = t0 + tl;
             tile[dl][tl] = (t < a.T && d < a.D) ? a.X[(long)t * a.ldx + d] : 0.0;
         }
     }
-    __syncthreads();
-    const int tg = tid & 63, tb = t0 + 4 * tg;
-    if (tb >= a.Kp) return;
+    const int w = tid >> 6, l = tid & 63, r = l >> 2, tb = 64 * w + 16 * (l & 3);
+    const long kt = t0 / 64 + w;
+    const bool live = kt * 64 < a.Kp;
+    const int d = d0 + r;
+    const long nkt = a.Kp / 64;
+    int8_t* const dst0 = a.P + (((long)blockIdx.y * nkt + kt) << 10) + l * 16;
+    const long plane = (long)a.Dq * a.Kp;
     for (int gz = 0; gz < G; ++gz) {
-        double om[4] = {1.0, 1.0, 1.0, 1.0};
-        if (a.Om) {
+        __syncthreads();                                   // the tile is staged / the previous neuron's weights are no longer read
+        if (a.Om) oms[tid] = t0 + tid < a.T ? a.Om[(long)(t0 + tid) * a.ldo + gz] : 0.0;
+        __syncthreads();
+        if (!live) continue;
+        const double scale = d < a.D ? ldexp(1.0, scale_exp(a.Om ? a.wmax[gz] * a.xmax[d] : a.xmax[d], a.beta)) : 0.0;
+        double v[16], vm[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) om[k] = tb + k < a.T ? a.Om[(long)(tb + k) * a.ldo + gz] : 0.0;
+        for (int k = 0; k < 16; ++k) {
+            const double x = tile[r][tb + k];
+            v[k] = rint((a.Om ? x * oms[tb + k] : x) * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
+            vm[k] = v[k] + MAGIC;                                   // exact: integers below 2^53
         }
-        for (int dl = tid >> 6; dl < PT_D; dl += 4) {
-            const int d = d0 + dl;
-            const double scale = d < a.D ? ldexp(1.0, scale_exp(a.Om ? a.wmax[gz] * a.xmax[d] : a.xmax[d])) : 0.0;
-            // the scaled integers as sign + three limbs |I| = a 2^34 + b 2^17 + c; residue = sign * ((a m34 + b m17 + c) mod p), folded
-            // to [-p/2, p/2] -- integer multiply-adds and a division by a compile-time constant per plane
-            int la[4], lb[4], lc[4], sg[4];
+        int8_t* dst = dst0 + (long)gz * NP * plane;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double v = rint(tile[dl][4 * tg + k] * om[k] * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
-                const double av = fabs(v);
-                const double hi = floor(av * 0x1p-34);                             // exact: av is an integer < 2^50
-                const double rem = av - hi * 0x1p34;
-                const double mid = floor(rem * 0x1p-17);
-                sg[k] = v < 0.0 ? -1 : 1;
-                la[k] = (int)hi; lb[k] = (int)mid; lc[k] = (int)(rem - mid * 0x1p17);
-            }
-            int8_t* dst = a.P + (((long)gz * NP) * a.Dq + d) * a.Kp + tb;
+        for (int q = 0; q < NP; ++q) {
+            unsigned b[16];
+            if (q == 0) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int p = MT.p[q];
-                unsigned w = 0;
+                for (int k = 0; k < 16; ++k) b[k] = (unsigned)__double2loint(vm[k]);      // mod 256: the low byte of the integer itself
+            } else {
+                const double pd = (double)MT.p[q], ip = 1.0 / pd;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int r = (la[k] * MT.m34[q] + lb[k] * MT.m17[q] + lc[k]) % p;      // < 2^16 * 255 + 2^17 * 255 + 2^17 < 2^26
-                    if (r > p / 2) r -= p;
-                    r *= sg[k];
-                    w |= (unsigned)(r & 0xff) << (8 * k);
+                for (int k = 0; k < 16; ++k) {
+                    const double qq = (v[k] * ip + MAGIC) - MAGIC;
+                    b[k] = (unsigned)__double2loint(fma(-pd, qq, vm[k]));
                 }
-                *reinterpret_cast<unsigned*>(dst + (long)q * a.Dq * a.Kp) = w;
             }
+            v4i out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned lo = __builtin_amdgcn_perm(b[4 * j + 1], b[4 * j], 0x0c0c0400u);
+                const unsigned hi = __builtin_amdgcn_perm(b[4 * j + 3], b[4 * j + 2], 0x0c0c0400u);
+                out[j] = (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            }
+            *reinterpret_cast<v4i*>(dst + (long)q * plane) = out;
         }
     }
 }
@@ -141,13 +147,16 @@ __global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a, int G) {
 // ------------------------------------------------------------------ int8 Gram of the planes, reduced mod p
 constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
 constexpr int STAGE_BYTES = (TM + TN) * BKB;
-constexpr int GRAM_LDS = NST * STAGE_BYTES;
+constexpr int GRAM_LDS = NST * STAGE_BYTES + 16;             // + the work ticket
+constexpr int KCH = 2000;                                    // K tiles between re-reductions: 128 + 128000 * 128 * 128 < 2^31
+constexpr int SB = 6, CH = 32;                               // clustered tile order: super-blocks of SB x SB tiles; work-list chunk per XCD
 
 struct GramArgs {
-    const int8_t* PA;                     // [NP][Dq][Kp]
-    const int8_t* PB;                     // [G][NP][Dq][Kp]
+    const int8_t* PA;                     // [NP] planes
+    const int8_t* PB;                     // [G][NP] planes
     int8_t* R;                            // [G][NP][Dq][Dq]
     int Dq; long Kp; int G;
+    int* sched;                           // 8 per-XCD work counters, zeroed before the launch
 };
 
 __device__ __forceinline__ int isqrt_tri_i(int t) {
@@ -157,42 +166,52 @@ __device__ __forceinline__ int isqrt_tri_i(int t) {
     return r;
 }
 
-__global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int ntm = g.Dq / TM;
-    const int ntiles = ntm * (ntm + 1) / 2;
-    // item = (neuron of the group, plane, tile), tile fastest: the workgroups resident together work on one plane pair and share its
-    // 256-row strips through L2 (plane-fastest order streamed every strip from HBM: 517 GB per launch, 5.3 TB/s, memory-bound)
-    const int tile = blockIdx.x % ntiles, q = (blockIdx.x / ntiles) % NP, gz = blockIdx.x / (ntiles * NP);
-    if (gz >= g.G) return;
-    const int tm = isqrt_tri_i(tile), tn = tile - tm * (tm + 1) / 2;
+// tile t of a plane's lower triangle in CLUSTERED order: super-blocks of SB x SB tiles, row by row (boustrophedon), so that a run of
+// ~32 consecutive tiles touches few distinct 256-row strips: the workgroups of an XCD, which take such a run together, share the
+// strips through their L2 (with the plain triangular order every workgroup streamed its own two strips: 2.2 instead of 3.7 POPS)
+__device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn) {
+    const int nsb = (ntm + SB - 1) / SB;
+    for (int I = 0; I < nsb; ++I) {
+        const int r0 = I * SB, nr = min(SB, ntm - r0);
+        for (int jj = 0; jj <= I; ++jj) {
+            const int J = (I & 1) ? I - jj : jj;
+            const int c0 = J * SB, nc = min(SB, ntm - c0);
+            const int cnt = I == J ? nr * (nr + 1) / 2 : nr * nc;
+            if (t < cnt) {
+                if (I == J) { const int r = isqrt_tri_i(t); tm = r0 + r; tn = c0 + t - r * (r + 1) / 2; }
+                else { tm = r0 + t / nc; tn = c0 + t % nc; }
+                return;
+            }
+            t -= cnt;
+        }
+    }
+    tm = tn = 0;
+}
+
+__device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds) {
     const int m0 = tm * TM, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int8_t* A = g.PA + (long)q * g.Dq * g.Kp;
-    const int8_t* B = g.PB + ((long)gz * NP + q) * g.Dq * g.Kp;
+    const long plane = (long)g.Dq * g.Kp;
+    const int8_t* A = g.PA + (long)q * plane;
+    const int8_t* B = g.PB + ((long)gz * NP + q) * plane;
     const int nkt = (int)(g.Kp / BKB);
 
-    // DMA: per K tile 512 rows x 64 B = 32 requests of 1 KiB (16 rows); wave w issues requests w, w+8, w+16, w+24.  Lane l of a request
+    // DMA: per K tile 512 rows x 64 B = 32 requests of 1 KiB (16 rows = one row block of the blocked plane layout: contiguous in memory,
+    // and a row block's K tiles follow each other -- with row-major planes a request was sixteen 64-byte pieces 100 KB apart and the
+    // kernel was bound by the L2 -> LDS path at 2.7 POPS).  Wave w issues requests w, w+8 (A rows) and w+16, w+24 (B rows).  Lane l
     // fills row 16 rq + l / 4, physical 16-byte chunk l % 4, with logical chunk (l % 4) ^ ((row >> 2) & 3)
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const char* gp[4];
     int loff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int rq = wv + 8 * i, row = 16 * rq + (lane >> 2);
-        const int lc = (lane & 3) ^ ((row >> 2) & 3);
-        const int8_t* base = row < TM ? A + (long)(m0 + row) * g.Kp : B + (long)(n0 + row - TM) * g.Kp;
-        gp[i] = reinterpret_cast<const char*>(base) + lc * 16;
+        const int rq = wv + 8 * i;
+        const int lc = (lane & 3) ^ ((lane >> 4) & 3);
+        const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.Kp : B + (long)(n0 + 16 * rq - TM) * g.Kp;
+        gp[i] = reinterpret_cast<const char*>(base) + (lane >> 2) * 64 + lc * 16;
         loff[i] = rq * 1024;
     }
-    auto dma = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
-            gp[i] += BKB;
-        }
-    };
     v16i acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -205,17 +224,24 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
         const int pc = (kk * 2 + fk) ^ ((row >> 2) & 3);
         return *reinterpret_cast<const v4i*>(lds + stage * STAGE_BYTES + row * BKB + pc * 16);
     };
-    // Pipeline: NST - 1 = 3 tiles requested ahead; fragments double-buffered in registers, every LDS read and DMA request issued in
-    // the shadow of an MFMA (order pinned with sched_barrier); the barrier sits in the MIDDLE of a K tile (after its first k-step):
-    // it publishes tile kt+1, whose first fragments are fetched during the second k-step, and frees the stage of tile kt-1 for the
-    // requests of tile kt+3.  Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
-    long gadv = BKB;                 // 0 once the last tile has been requested: the cursors stop and the last tile is requested again
-    auto dma_piece = [&](int stage, int i) {      // (into a stage nobody reads any more) -- no branch in front of a request
+    // Pipeline: tiles are requested NST - 1 = 3 ahead, two requests per k-step (requests 0, 1 of tile kt+3 in the second k-step of tile
+    // kt, requests 2, 3 in the first k-step of tile kt+1); fragments double-buffered in registers, every LDS read and DMA request issued
+    // in the shadow of an MFMA (order pinned with sched_barrier); the barrier sits in the MIDDLE of a K tile (after its first k-step):
+    // it publishes tile kt+1, whose first fragments are fetched during the second k-step, and frees the stage of tile kt-1.
+    // Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
+    long gadv = 1024, gadv2 = 1024;   // 0 once the last tile has been requested: the cursors stop and the last tile is requested again
+    auto dma_piece = [&](int stage, int i, long adv) {      // (into a stage nobody reads any more) -- no branch in front of a request
         __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
-        gp[i] += gadv;
+        gp[i] += adv;
     };
-    for (int p = 0; p < NST - 1; ++p) if (p < nkt) dma(p);
-    if (nkt >= NST - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue (nkt >= 4): tiles 0, 1 and the first half of tile 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(0, i, 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(1, i, 1024);
+    dma_piece(2, 0, 1024);
+    dma_piece(2, 1, 1024);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     v4i F[2][6];
@@ -224,33 +250,52 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
     };
 #pragma unroll
     for (int f = 0; f < 6; ++f) F[0][f] = rd(0, 0, f);
+    const double pq = (double)c_mod[q], ipq = 1.0 / pq;
+    auto reduce = [&](int v) {                              // symmetric representative of v mod p (exact: |v| < 2^31)
+        const double x = (double)v;
+        return (int)fma(-pq, rint(x * ipq), x);
+    };
     int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int nxt = cur == NST - 1 ? 0 : cur + 1;
-        const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes tile kt+NST-1
-        if (kt + NST >= nkt) gadv = 0;
-        // ---- first k-step (set 0): prefetch the fragments of this tile's second k-step
+    for (int kc = 0; kc < nkt; kc += KCH) {
+        const int kend = min(nkt, kc + KCH);
+        for (int kt = kc; kt < kend; ++kt) {
+            const int nxt = cur == NST - 1 ? 0 : cur + 1;
+            const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes the first half of tile kt+3
+            const int dst2 = cur ^ 2;                               // the stage of tile kt-2 takes the second half of tile kt+2
+            if (kt + NST >= nkt) gadv = 0;
+            if (kt + NST - 1 >= nkt) gadv2 = 0;
+            // ---- first k-step (set 0): prefetch the fragments of this tile's second k-step
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0][m >> 1], F[0][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
-            if (m < 6) F[1][m] = rd(cur, 1, m);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ---- second k-step (set 1): prefetch the first fragments of tile kt+1, request tile kt+3
+            for (int m = 0; m < 8; ++m) {
+                acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0][m >> 1], F[0][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
+                if (m < 6) F[1][m] = rd(cur, 1, m);
+                if (m == 3 || m == 7) dma_piece(dst2, 2 + (m >> 2), gadv2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- second k-step (set 1): prefetch the first fragments of tile kt+1
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[1][m >> 1], F[1][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
-            if (m < 6) F[0][m] = rd(nxt, 0, m);
-            if (m & 1) dma_piece(dst, m >> 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < 8; ++m) {
+                acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[1][m >> 1], F[1][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
+                if (m < 6) F[0][m] = rd(nxt, 0, m);
+                if (m == 3 || m == 7) dma_piece(dst, m >> 2, gadv);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur = nxt;
         }
-        cur = nxt;
+        if (kend < nkt) {                                           // long data sets: bring the int32 sums back below p before they can overflow
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = reduce(acc[i][j][r]);
+        }
     }
-    // epilogue: reduce mod p (symmetric) and store bytes.  C/D layout of 32x32 i32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    const double p = (double)c_mod[q], ip = 1.0 / p;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant last requests must have landed before the LDS is reused
+    // epilogue: reduce mod p and store bytes.  C/D layout of 32x32 i32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     int8_t* R = g.R + ((long)gz * NP + q) * g.Dq * g.Dq;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -260,11 +305,45 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-                const double v = (double)acc[i][j][r];
-                double rr = fma(-p, rint(v * ip), v);
-                if (rr > 0.5 * p) rr -= p; else if (rr < -0.5 * p) rr += p;
-                R[(long)row * g.Dq + col] = (int8_t)(int)rr;
+                R[(long)row * g.Dq + col] = (int8_t)(reduce(acc[i][j][r]) & 0xff);   // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
             }
+}
+
+// persistent: one workgroup per CU.  The items (neuron of the group, plane, tile in clustered order) are cut into chunks of CH; chunk c
+// belongs to XCD c % 8; a workgroup reads the XCC it runs on and pulls the next item of that XCD's list, stealing from the next XCD when
+// its own list is exhausted.  Placement is used for speed only -- any placement gives the same result.
+__global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int* ticket = reinterpret_cast<int*>(lds + NST * STAGE_BYTES);
+    const int ntm = g.Dq / TM;
+    const int ntiles = ntm * (ntm + 1) / 2;
+    const int total = ntiles * NP * g.G;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    for (;;) {
+        __syncthreads();                                   // also drains the previous item's last (redundant) requests: vmcnt(0)
+        if (threadIdx.x == 0) {
+            int w = -1;
+            for (int hop = 0; hop < 8 && w < 0; ++hop) {
+                const int y = (int)((xcc + hop) & 7u);
+                const int it = atomicAdd(&g.sched[y], 1);
+                const long cand = ((long)(it / CH) * 8 + y) * CH + it % CH;
+                if (cand < total) w = (int)cand;
+            }
+            if (w >= 0) {
+                int tm, tn;
+                clustered_tile(w % ntiles, ntm, tm, tn);
+                ticket[1] = w / ntiles; ticket[2] = tm; ticket[3] = tn;
+            }
+            ticket[0] = w;
+        }
+        __syncthreads();
+        if (ticket[0] < 0) break;
+        const int pair = __builtin_amdgcn_readfirstlane(ticket[1]);
+        const int tm = __builtin_amdgcn_readfirstlane(ticket[2]), tn = __builtin_amdgcn_readfirstlane(ticket[3]);
+        i8_gram_item(g, pair / NP, pair % NP, tm, tn, lds);
+    }
 }
 
 // ------------------------------------------------------------------ CRT reconstruction into J
@@ -272,7 +351,7 @@ struct CrtArgs {
     const int8_t* R;                      // [G][NP][Dq][Dq]
     const double* xmax; const double* wmax;
     double* J; long ldj; long strideJ;    // [G] slots
-    int D, Dq, G, accumulate;
+    int D, Dq, G, accumulate, beta;
 };
 
 __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
@@ -295,7 +374,7 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
     double s = (double)v[NP - 1];
 #pragma unroll
     for (int q = NP - 2; q >= 0; --q) s = s * (double)MT.p[q] + (double)v[q];
-    const int e = scale_exp(a.xmax[i]) + scale_exp(a.wmax[gz] * a.xmax[j]);
+    const int e = scale_exp(a.xmax[i], a.beta) + scale_exp(a.wmax[gz] * a.xmax[j], a.beta);
     const double val = ldexp(s, -e);
     double* dst = a.J + (long)gz * a.strideJ + (long)i * a.ldj + j;
     *dst = a.accumulate ? *dst + val : val;
@@ -307,13 +386,22 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
 // time bins per plane row: a multiple of the 64-byte K tile, at least four tiles (the Gram pipeline keeps three requested ahead)
 static long pgl_i8_kp(int T) { const long k = ((long)T + 63) / 64 * 64; return k < 256 ? 256 : k; }
 
+// bits of the scaled operands: the largest beta <= 50 with T 2^(2 beta) < prod(p) / 2, so that the CRT range holds the integer Gram for
+// any data (50 up to T = 112 000, 49 up to 451 000, ...)
+static int pgl_i8_beta(int T) {
+    double l2 = 0.0;
+    for (int q = 0; q < NP; ++q) l2 += std::log2((double)MT.p[q]);
+    const int b = (int)std::floor((l2 - 1.0 - std::log2((double)(T < 1 ? 1 : T))) * 0.5 - 1e-9);
+    return b < 50 ? b : 50;
+}
+
 size_t pgl_k_i8_plane_bytes(int D, int T) {
     const long Dq = (D + 255) / 256 * 256, Kp = pgl_i8_kp(T);
-    return (size_t)15 * Dq * Kp;
+    return (size_t)NP * Dq * Kp;
 }
 size_t pgl_k_i8_residue_bytes(int D) {
     const long Dq = (D + 255) / 256 * 256;
-    return (size_t)15 * Dq * Dq;
+    return (size_t)NP * Dq * Dq;
 }
 
 // column maxima of |V| (out must be zero-filled by the caller: maxima are merged with atomicMax)
@@ -328,28 +416,42 @@ int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const
                     hipStream_t st) {
     const int Dq = (D + 255) / 256 * 256;
     const long Kp = pgl_i8_kp(T);
-    PlaneArgs a{X, ldx, Om, ldo, xmax, wmax, P, T, D, Dq, Kp};
-    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
+    PlaneArgs a{X, ldx, Om, ldo, xmax, wmax, P, T, D, Dq, Kp, pgl_i8_beta(T)};
+    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + PT_T - 1) / PT_T), Dq / PT_D), dim3(256), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
 
-int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, const double* xmax, const double* wmax, double* J, long ldj, long strideJ,
-                  int T, int D, int G, int accumulate, hipStream_t st) {
-    if (T > 131072) { pgl_set_error("i8 gram: T = %d > 131072 would overflow the int32 accumulators", T); return PGL_ERR_ARG; }
+int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, int G, hipStream_t st) {
     const int Dq = (D + 255) / 256 * 256;
     const long Kp = pgl_i8_kp(T);
     static bool attr = false;
+    static int n_cu = 0;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(i8_gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GRAM_LDS);
         if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGL_ERR_HIP; }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n_cu <= 0) n_cu = 256;
         attr = true;
     }
     const int ntm = Dq / TM, ntiles = ntm * (ntm + 1) / 2;
-    GramArgs g{PA, PB, R, Dq, Kp, G};
-    hipLaunchKernelGGL(i8_gram_kernel, dim3((unsigned)(ntiles * 15 * G)), dim3(512), GRAM_LDS, st, g);
+    const long total = (long)ntiles * NP * G;
+    if (total <= 0) return PGL_OK;
+    if (total > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
+    GramArgs g{PA, PB, R, Dq, Kp, G, pgl_sched_slot(st)};
+    if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
+    hipLaunchKernelGGL(i8_gram_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), GRAM_LDS, st, g);
     PGL_CHECK_LAUNCH();
-    CrtArgs c{R, xmax, wmax, J, ldj, strideJ, D, Dq, G, accumulate};
+    return PGL_OK;
+}
+
+int pgl_k_i8_crt(const int8_t* R, const double* xmax, const double* wmax, double* J, long ldj, long strideJ, int T, int D, int G, int accumulate,
+                 hipStream_t st) {
+    const int Dq = (D + 255) / 256 * 256;
+    if (G <= 0) return PGL_OK;
+    CrtArgs c{R, xmax, wmax, J, ldj, strideJ, D, Dq, G, accumulate, pgl_i8_beta(T)};
     hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 255) / 256, D, G), dim3(256), 0, st, c);
     PGL_CHECK_LAUNCH();
     return PGL_OK;

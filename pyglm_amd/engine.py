@@ -102,11 +102,13 @@ class GibbsEngine(object):
             raise ValueError("B=%d too large for the proposal window" % self.B)
         self.datasets = []
         self.stream = torch.cuda.current_stream(self.dev)
-        # the likelihood Gram X'OX: "fp64" = the fp64-MFMA kernel (default); "int8" = exact integer arithmetic on the int8 MFMA (15 residue
-        # planes + CRT, pgl_i8_*; operands rounded to 50-bit fixed point per column -- error at the level of the fp64 product's own)
+        # the likelihood Gram X'OX: "fp64" = the fp64-MFMA kernel; "int8" = exact integer arithmetic on the int8 MFMA (15 residue planes +
+        # CRT, pgl_i8_*; operands rounded to 50-bit fixed point per column -- error at the level of the fp64 product's own); "auto"
+        # (default) takes the integer path per data set where it is the faster one and its planes fit in memory (_use_int8)
         import os
-        self.gram = gram or os.environ.get("PGL_GRAM", "fp64")
-        assert self.gram in ("fp64", "int8")
+        self.gram = gram or os.environ.get("PGL_GRAM", "auto")
+        assert self.gram in ("auto", "fp64", "int8")
+        self._i8_scratch = None
         per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
         if batch is None:
             free, _ = torch.cuda.mem_get_info(self.dev)
@@ -226,13 +228,15 @@ class GibbsEngine(object):
         ds.Psi = self._z(T, self.ldn)
         ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
         ds.llpart = self._z(_lib.load().pgl_pg_loglik_partials(T), self.nloc)
-        if self.gram == "int8" and self.obs != 2:
+        ds.int8 = self._use_int8(T)
+        if ds.int8:
             # residue planes of X (once per data set) and the column maxima that fix the fixed-point scales
             lib = _lib.load()
             ds.xmax = self._z(self.D)
             call("pgl_i8_colmax", ptr(ds.X), self.Dp, T, self.D, ptr(ds.xmax), st)
             ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T), dtype=torch.int8, device=self.dev)
             call("pgl_i8_planes", ptr(ds.X), self.Dp, None, 0, ptr(ds.xmax), None, ptr(ds.PA), T, self.D, 1, st)
+            self._i8_reserve(T)
             torch.cuda.synchronize(self.dev)
         if self.obs == 2:
             ones = self._z(ds.Tp, 2)
@@ -241,6 +245,41 @@ class GibbsEngine(object):
                  int(len(self.datasets) > 1), st)
             torch.cuda.synchronize(self.dev)
         return ds
+
+    # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
+    I8_GROUP = 4          # neurons converted and multiplied per launch (their planes are 15 T D bytes each)
+    I8_MIN_D, I8_MIN_T = 1024, 2048
+
+    def _i8_need(self, T, G):
+        lib = _lib.load()
+        return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D))
+
+    def _use_int8(self, T):
+        """the Gram of a data set goes through the int8 MFMA if asked for, or (auto) if the shape is one where it is faster than the fp64
+        kernel (256 x 256 tiles, 15 planes: not for small D or short T) and X's planes plus one neuron's scratch fit beside everything else"""
+        if self.obs == 2 or self.design_only or self.gram == "fp64":
+            return False
+        if self.gram == "int8":
+            return True
+        if self.D < self.I8_MIN_D or T < self.I8_MIN_T:
+            return False
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        have = self._i8_scratch[0] if self._i8_scratch else 0
+        return _lib.load().pgl_i8_plane_bytes(self.D, T) + max(0, self._i8_need(T, 1) - have) < 0.8 * free
+
+    def _i8_reserve(self, T):
+        """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the longest data set seen so far"""
+        lib = _lib.load()
+        import os
+        have = self._i8_scratch[0] if self._i8_scratch else 0
+        if have >= self._i8_need(T, 1) and self._i8_scratch[1] >= T:
+            return
+        self._i8_scratch = None
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // self._i8_need(T, 1))))
+        self._i8_scratch = (self._i8_need(T, G), T, G, torch.empty(G * lib.pgl_i8_plane_bytes(self.D, T), dtype=torch.int8, device=self.dev),
+                            torch.empty(G * lib.pgl_i8_residue_bytes(self.D), dtype=torch.int8, device=self.dev), self._z(self.nb))
 
     def set_noise(self, eta):
         """noise variances eta (nloc,) of the Gaussian observation model (regression.py:380-398)"""
@@ -370,42 +409,36 @@ class GibbsEngine(object):
             call("pgl_scaled_gram", ptr(self.G0), ldj, ctypes.c_void_p(self.inv_eta.data_ptr() + 8 * s), ptr(J), ldj, ldj * ldj, D, nbb, st)
             self._toc(h)
             return
-        if self.gram == "int8":
-            return self._gram_int8(s, nbb, J)
         for i, ds in enumerate(self.datasets):
+            if ds.int8:
+                self._gram_int8(i, ds, s, nbb, J)
+                continue
             h = self._tic("gram", float(nbb) * ds.T * D * (D + 1))     # algorithmic flops: lower triangle, 2 flop per MAC
             call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * s), 2 * ldn, ds.Tp, D, nbb, ptr(J), ldj,
                  ldj * ldj, int(i > 0), st)
             self._toc(h)
 
-    def _gram_int8(self, s, nbb, J):
-        import os
+    def _gram_int8(self, i, ds, s, nbb, J):
         """the same Gram through pgl_i8_* in groups of G neurons (the 15 residue planes of omega_n X are 15 T D bytes per neuron)"""
         D, ldn, Dp, ldj = self.D, self.ldn, self.Dp, self.ldj
         st = self._st()
-        lib = _lib.load()
-        Tmax = max(ds.T for ds in self.datasets)
-        pbytes, rbytes = lib.pgl_i8_plane_bytes(D, Tmax), lib.pgl_i8_residue_bytes(D)
-        if getattr(self, "_i8_scratch", None) is None or self._i8_scratch[0] < pbytes:
-            free, _ = torch.cuda.mem_get_info(self.dev)
-            G = int(max(1, min(int(os.environ.get('PGL_I8_GROUP', 4)), self.nb, (free * 0.85) // (pbytes + rbytes))))
-            self._i8_scratch = (pbytes, G, torch.empty(G * pbytes, dtype=torch.int8, device=self.dev),
-                                torch.empty(G * rbytes, dtype=torch.int8, device=self.dev), self._z(self.nb))
-        _, G, PB, R, wmax = self._i8_scratch
-        for i, ds in enumerate(self.datasets):
-            om = ctypes.c_void_p(ds.OK.data_ptr() + 8 * s)
-            wmax.zero_()
-            call("pgl_i8_colmax", om, 2 * ldn, ds.T, nbb, ptr(wmax), st)
-            for g0 in range(0, nbb, G):
-                gz = min(G, nbb - g0)
-                h = self._tic("gram.planes", 8.0 * gz * ds.T * D)
-                call("pgl_i8_planes", ptr(ds.X), Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * (s + g0)), 2 * ldn, ptr(ds.xmax),
-                     ctypes.c_void_p(wmax.data_ptr() + 8 * g0), ptr(PB), ds.T, D, gz, st)
-                self._toc(h)
-                h = self._tic("gram", float(gz) * ds.T * D * (D + 1))
-                call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ptr(ds.xmax), ctypes.c_void_p(wmax.data_ptr() + 8 * g0),
-                     ctypes.c_void_p(J.data_ptr() + 8 * g0 * ldj * ldj), ldj, ldj * ldj, ds.T, D, gz, int(i > 0), st)
-                self._toc(h)
+        _, _, G, PB, R, wmax = self._i8_scratch
+        om = ctypes.c_void_p(ds.OK.data_ptr() + 8 * s)
+        wmax.zero_()
+        call("pgl_i8_colmax", om, 2 * ldn, ds.T, nbb, ptr(wmax), st)
+        for g0 in range(0, nbb, G):
+            gz = min(G, nbb - g0)
+            h = self._tic("gram.planes", 8.0 * gz * ds.T * D)
+            call("pgl_i8_planes", ptr(ds.X), Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * (s + g0)), 2 * ldn, ptr(ds.xmax),
+                 ctypes.c_void_p(wmax.data_ptr() + 8 * g0), ptr(PB), ds.T, D, gz, st)
+            self._toc(h)
+            h = self._tic("gram.int8", float(gz) * ds.T * D * (D + 1))
+            call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, st)
+            self._toc(h)
+            h = self._tic("gram.crt", 15.0 * gz * D * (D + 1) / 2)
+            call("pgl_i8_crt", ptr(R), ptr(ds.xmax), ctypes.c_void_p(wmax.data_ptr() + 8 * g0),
+                 ctypes.c_void_p(J.data_ptr() + 8 * g0 * ldj * ldj), ldj, ldj * ldj, ds.T, D, gz, int(i > 0), st)
+            self._toc(h)
 
     def _post(self, s, nbb, slot, a_host, det, dev, skip):
         """posterior assembly, collapsed flips and weight draw of local neurons [s, s+nbb) from J slot `slot`"""

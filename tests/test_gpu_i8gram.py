@@ -7,12 +7,21 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-MODULI = [255, 254, 253, 251, 247, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193]
-BETA = 50
+MODULI = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197]
 
 
-def _scale_exp(m):
-    return np.where(m > 0, BETA - np.frexp(np.maximum(m, 1e-300))[1], 0).astype(np.int64)
+def _beta(T):
+    """bits of the scaled operands: T 2^(2 beta) < prod(p) / 2 (pgl_i8gram.hip: pgl_i8_beta)"""
+    return min(50, int(np.floor((sum(np.log2(p) for p in MODULI) - 1.0 - np.log2(T)) * 0.5 - 1e-9)))
+
+
+def _scale_exp(m, T):
+    return np.where(m > 0, _beta(T) - np.frexp(np.maximum(m, 1e-300))[1], 0).astype(np.int64)
+
+
+def _planes(P, n, Dq, Kp):
+    """blocked plane layout [row / 16][K tile][row % 16][64 B] -> (n, Dq, Kp)"""
+    return P.reshape(n, Dq // 16, Kp // 64, 16, 64).transpose(0, 1, 3, 2, 4).reshape(n, Dq, Kp)
 
 
 def _setup(T, D, G, seed=0):
@@ -49,26 +58,27 @@ def test_residue_planes_match_numpy():
     call("pgl_i8_planes", ptr(Xd), D, None, 0, ptr(xmax), None, ptr(PA), T, D, 1, None)
     call("pgl_i8_planes", ptr(Xd), D, ptr(Od), G, ptr(xmax), ptr(wmax), ptr(PB), T, D, G, None)
     torch.cuda.synchronize()
-    PA = PA.cpu().numpy().reshape(15, Dq, Kp).astype(np.int64)
-    PB = PB.cpu().numpy().reshape(G, 15, Dq, Kp).astype(np.int64)
-    eA = _scale_exp(np.abs(X).max(0))
+    PA = _planes(PA.cpu().numpy(), 15, Dq, Kp).astype(np.int64)
+    PB = _planes(PB.cpu().numpy(), G * 15, Dq, Kp).reshape(G, 15, Dq, Kp).astype(np.int64)
+    assert _beta(T) == 50 and _beta(112000) == 50 and _beta(113000) == 49 and _beta(200000) == 49
+    eA = _scale_exp(np.abs(X).max(0), T)
     IA = np.rint(np.ldexp(X, eA[None, :].astype(np.int32))).astype(np.int64)          # (T, D), |.| < 2^50
-    assert np.abs(IA).max() < 2 ** BETA
+    assert np.abs(IA).max() < 2 ** 50
     for q, p in enumerate(MODULI):
         got = PA[q, :D, :T]
-        assert not ((got - IA.T) % p).any() and np.abs(got).max() <= p // 2            # a representative of the residue in [-p/2, p/2]
+        assert not ((got - IA.T) % p).any() and got.min() >= -128 and got.max() <= 127   # a signed-byte representative of the residue
         assert not PA[q, D:].any() and not PA[q, :, T:].any()                          # padding rows / time bins are zero
     for g in range(G):
         V = Om[:, g:g + 1] * X
-        fB = _scale_exp(Om[:, g].max() * np.abs(X).max(0))
+        fB = _scale_exp(Om[:, g].max() * np.abs(X).max(0), T)
         IB = np.rint(np.ldexp(V, fB[None, :].astype(np.int32))).astype(np.int64)
         for q in (0, 7, 14):
             p = MODULI[q]
             got = PB[g, q, :D, :T]
-            assert not ((got - IB.T) % p).any() and np.abs(got).max() <= p // 2
+            assert not ((got - IB.T) % p).any() and got.min() >= -128 and got.max() <= 127
 
 
-@pytest.mark.parametrize("T,D,G", [(5000, 300, 3), (20000, 520, 2)])
+@pytest.mark.parametrize("T,D,G", [(5000, 300, 3), (20000, 520, 2), (140000, 40, 1), (300, 1700, 1)])
 def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G):
     import torch
     from pyglm_amd._lib import call, ptr, load
@@ -82,14 +92,15 @@ def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G):
     J = torch.zeros(G, ldj, ldj, dtype=torch.float64, device=dev)
     call("pgl_i8_planes", ptr(Xd), D, None, 0, ptr(xmax), None, ptr(PA), T, D, 1, None)
     call("pgl_i8_planes", ptr(Xd), D, ptr(Od), G, ptr(xmax), ptr(wmax), ptr(PB), T, D, G, None)
-    call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 0, None)
+    call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), T, D, G, None)
+    call("pgl_i8_crt", ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 0, None)
     torch.cuda.synchronize()
     Ji = J.cpu().numpy()[:, :D, :D]
     # (a) the exact integer answer: S = A'B on the scaled integers (Python ints), J = S 2^-(eA + fB)
-    eA = _scale_exp(np.abs(X).max(0))
+    eA = _scale_exp(np.abs(X).max(0), T)
     IA = np.rint(np.ldexp(X, eA[None, :].astype(np.int32))).astype(np.int64)
     for g in (0, G - 1):
-        fB = _scale_exp(Om[:, g].max() * np.abs(X).max(0))
+        fB = _scale_exp(Om[:, g].max() * np.abs(X).max(0), T)
         IB = np.rint(np.ldexp(Om[:, g:g + 1] * X, fB[None, :].astype(np.int32))).astype(np.int64)
         cols = [0, 1, 2, 5, D // 2, D - 1]
         S = IA.astype(object).T.dot(IB[:, cols].astype(object))                       # exact big-integer product, (D, len(cols))
@@ -118,7 +129,7 @@ def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G):
         e_f64 = float(np.max((np.abs(Jn[g] - ref) / den)[low]))
         assert e_int < 5e-15 and e_int < 20 * max(e_f64, 2e-16), (e_int, e_f64)
     # accumulate flag (second data set)
-    call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 1, None)
+    call("pgl_i8_crt", ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 1, None)
     torch.cuda.synchronize()
     np.testing.assert_allclose(np.tril(J.cpu().numpy()[0, :D, :D]), 2 * np.tril(Ji[0]), rtol=1e-15)
 

@@ -15,6 +15,13 @@ __global__ __launch_bounds__(THR) void k_reg(int* out, int iters) {
     v4i a[TM], b[TN];
     for (int i = 0; i < TM; ++i) a[i] = v4i{(int)threadIdx.x, i, 3, 4};
     for (int j = 0; j < TN; ++j) b[j] = v4i{j, (int)threadIdx.x * 7, 1, 2};
+    if (iters < 0) {        // random operand bytes (power: the multiplier arrays toggle as they do on real residues)
+        iters = -iters;
+        unsigned h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+        auto nx = [&] { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (int)h; };
+        for (int i = 0; i < TM; ++i) a[i] = v4i{nx(), nx(), nx(), nx()};
+        for (int j = 0; j < TN; ++j) b[j] = v4i{nx(), nx(), nx(), nx()};
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -69,11 +76,18 @@ static void timeit(const char* name, double ops_per_launch, F launch) {
     printf("%-58s %8.3f ms  %8.1f TOPS\n", name, ms, ops_per_launch / (ms * 1e-3) * 1e-12);
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
     int* out; CK(hipMalloc(&out, sizeof(int) * 1024 * cus * 2));
     const double mfma_ops = 32.0 * 32 * 32 * 2;
+    if (argc > 1) {     // sustained register-only rate: argv[1] = +1 constant operands, -1 random operands; ~6 s
+        const int sgn = atoi(argv[1]);
+        for (int rep = 0; rep < 12; ++rep)
+            timeit(sgn < 0 ? "reg 4x2 512 thr/CU, random operands, sustained" : "reg 4x2 512 thr/CU, constant operands, sustained", (double)cus * 8 * 4000000.0 * 8 * mfma_ops,
+                   [&] { k_reg<4, 2, 512><<<cus, 512>>>(out, sgn * 4000000); });
+        return 0;
+    }
 #define REG(TM, TN, THR, IT) timeit("reg  " #TM "x" #TN " tiles, " #THR " thr/CU", (double)cus * (THR / 64) * IT * TM * TN * mfma_ops, [&] { k_reg<TM, TN, THR><<<cus, THR>>>(out, IT); })
     REG(2, 2, 256, 20000); REG(4, 2, 256, 10000); REG(4, 4, 256, 5000); REG(2, 2, 512, 20000); REG(4, 2, 512, 10000);
 #define LDSB(TM, TN, BKB, PAD, SHARE, THR, IT)                                                                                   \
