@@ -230,7 +230,7 @@ def main():
                 except Exception:
                     tr = None
             out["dtype"] = "f64 (likelihood Gram: exact integer arithmetic on i8 residue planes, CRT back to f64)"
-            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_32x32x32_i8; 15 residue planes of 4 neurons per launch)",
+            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_32x32x32_i8; 15 residue planes of %d neurons per launch)" % (model.engine._i8_scratch[2] if model.engine._i8_scratch else 0),
                                "achieved": ach, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS, "traffic": tr,
                                "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"],
                                "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,

@@ -247,7 +247,7 @@ class GibbsEngine(object):
         return ds
 
     # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
-    I8_GROUP = 4          # neurons converted and multiplied per launch (their planes are 15 T D bytes each)
+    I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are 15 T D bytes each)
     I8_MIN_D, I8_MIN_T = 1024, 2048
 
     def _i8_need(self, T, G):

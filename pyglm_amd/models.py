@@ -300,12 +300,40 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
             net.resample((self.adjacency, self.weights))
         finally:
             npr.set_state(state)
+        if hasattr(net, "weight_blocks"):
+            # one shared block (+ one for self-connections): pushed as such -- the (N, N, B, B) expansion of sigma_W is 210 MB at N = 1024,
+            # a fifth of a second of host time per sweep on every rank, and nothing on the hot path reads it
+            mu_off, S_off, mu_self, S_self = net.weight_blocks()
+            rho = net.rho
+            for n, reg in enumerate(self.regressions):
+                reg._push_block_prior(mu_off, S_off, mu_self, S_self, n, rho[n])
+            self._cache_block_hypers(mu_off, S_off, mu_self, S_self, rho)
+            return
         sigma, mu, rho = net.sigma_W, net.mu_W, net.rho
         for n, reg in enumerate(self.regressions):
             reg.S_w = sigma[n]
             reg.mu_w = mu[n]
             reg.rho = rho[n]
         self._cache_pushed_hypers(sigma, mu, rho)
+
+    def _cache_block_hypers(self, mu_off, S_off, mu_self, S_self, rho):
+        """natural-parameter terms of the shard's rows for a (shared block, self block) push: two table entries and the labels"""
+        from .engine import prior_terms, BlockPrior
+        n0, n1, N, B = self.n0, self.n1, self.N, self.B
+        regs = self.regressions[n0:n1]
+        nl = n1 - n0
+        label = np.zeros((nl, N), dtype=np.int64)
+        S_u, mu_u = [S_off], [mu_off]
+        if S_self is not None:
+            S_u.append(S_self)
+            mu_u.append(mu_self)
+            label[np.arange(nl), np.arange(n0, n1)] = 1
+        Jw_u, hw_u, _, _, c0_u = prior_terms(np.array(S_u)[None], np.array(mu_u)[None], np.ones(1), np.zeros(1))
+        prior = BlockPrior(Jw_u[0], hw_u[0], c0_u[0], label)
+        S_b = np.array([r.S_b[0, 0] for r in regs])
+        mu_b = np.array([r.mu_b[0] for r in regs])
+        Jb = 1.0 / S_b
+        self._hyper_cache = (tuple(r._hyp_version for r in regs), (np.array(rho[n0:n1], dtype=float), prior, None, Jb, Jb * mu_b, None))
 
     def _cache_pushed_hypers(self, sigma, mu, rho):
         """natural-parameter terms of the shard's rows for the hyper-parameters just pushed.  Network priors produce a

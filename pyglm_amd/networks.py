@@ -89,6 +89,12 @@ class _IndependentGaussianMixin(_NetworkModel):
             out[r - n0, r] = diag
         return out
 
+    def weight_blocks(self):
+        """(mu, Sigma) of an ordinary connection and of a self-connection (None, None if not special): all there is to mu_W / sigma_W"""
+        if self.is_diagonal_weight_special:
+            return self._gaussian.mu, self._gaussian.sigma, self._self_gaussian.mu, self._self_gaussian.sigma
+        return self._gaussian.mu, self._gaussian.sigma, None, None
+
     def mu_W_rows(self, n0, n1):
         return self._rows(self._gaussian.mu, self._self_gaussian.mu if self.is_diagonal_weight_special else None, n0, n1)
 

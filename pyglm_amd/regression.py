@@ -11,6 +11,20 @@ import numpy.random as npr
 from .utils.utils import logistic, expand_scalar, expand_cov
 
 
+class _BlockRows(object):
+    """N copies of one block, with row n replaced by another: what a network prior pushes into a regression (networks.py:96-130)"""
+
+    def __init__(self, off, own, n):
+        self.off, self.own, self.n = off, own, n
+
+    def expand(self, N):
+        out = np.empty((N,) + self.off.shape)
+        out[:] = self.off
+        if self.own is not None:
+            out[self.n] = self.own
+        return out
+
+
 class _SparseScalarRegressionBase(object):
     """spike-and-slab regression y_t ~ sum_n a_n w_n.x_{t,n} + b  (reference regression.py:40-92)."""
     _obs = None
@@ -38,10 +52,24 @@ class _SparseScalarRegressionBase(object):
         setattr(self, name, value)
         self._hyp_version = self._hyp_version + 1
 
+    def _get_rows(self, name):
+        v = getattr(self, name)
+        if isinstance(v, _BlockRows):          # pushed by a network prior as (shared block, own block): expanded on first read
+            v = v.expand(self.N)
+            setattr(self, name, v)
+        return v
+
     rho = property(lambda self: self._rho, lambda self, v: self._set("_rho", expand_scalar(v, (self.N,))))
-    mu_w = property(lambda self: self._mu_w, lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B))))
+    mu_w = property(lambda self: self._get_rows("_mu_w"), lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B))))
     mu_b = property(lambda self: self._mu_b, lambda self, v: self._set("_mu_b", expand_scalar(v, (1,))))
-    S_w = property(lambda self: self._S_w, lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B))))
+    S_w = property(lambda self: self._get_rows("_S_w"), lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B))))
+
+    def _push_block_prior(self, mu_off, S_off, mu_self, S_self, n, rho_row):
+        """the hyper-parameter push of models.py:233-236 for a prior with one shared weight block and (optionally) one for the
+        self-connection n: same values as assigning the expanded (N, B) / (N, B, B) arrays, which are only built if somebody reads them"""
+        self._mu_w = _BlockRows(mu_off, mu_self, n)
+        self._S_w = _BlockRows(S_off, S_self, n)
+        self._set("_rho", expand_scalar(rho_row, (self.N,)))
 
     @property
     def S_b(self):

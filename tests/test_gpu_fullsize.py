@@ -53,6 +53,26 @@ def test_gram_identities_at_cfg3_shape():
     assert ((got - ref)[mask]).abs().max().item() <= 1e-11 * ref.abs().max().item()
     blk = J[3, 1280:1408, 1280:1408]                                                             # a diagonal tile is written in full
     assert (blk - blk.t()).abs().max().item() <= 1e-12 * blk.abs().max().item()
+    # the same four Grams through the integer matrix cores (what gram='auto' runs at this shape): residue planes, int8 GEMM mod p, CRT
+    assert ds.int8 and eng._i8_scratch is not None
+    _, _, G8, PB, R, wmax = eng._i8_scratch
+    assert G8 >= 4
+    wmax.zero_()
+    call("pgl_i8_colmax", ptr(W), 4, T, 4, ptr(wmax), None)
+    call("pgl_i8_planes", ptr(ds.X), Dp, ptr(W), 4, ptr(ds.xmax), ptr(wmax), ptr(PB), T, D, 4, None)
+    call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), T, D, 4, None)
+    J8 = torch.zeros(4, ldj, ldj, dtype=torch.float64, device="cuda")
+    call("pgl_i8_crt", ptr(R), ptr(ds.xmax), ptr(wmax), ptr(J8), ldj, ldj * ldj, T, D, 4, 0, None)
+    torch.cuda.synchronize()
+    L8 = [torch.tril(J8[k, :D, :D]) for k in range(4)]
+    for k in range(4):
+        assert (L8[k] - L[k]).abs().max().item() <= 1e-12 * L[k].abs().max().item()            # against the fp64 kernel
+        tr = torch.diagonal(L8[k]).sum().item()
+        want = (W[:T, k, None] * X * X).sum().item()
+        assert abs(tr - want) <= 1e-11 * abs(want)
+    assert (L8[2] - (L8[0] + 2 * L8[1])).abs().max().item() <= 1e-12 * scale
+    assert ((J8[3, :D, cols] - ref)[mask]).abs().max().item() <= 1e-11 * ref.abs().max().item()
+    del J8, L8
     # border sums  [Omega|Kappa]' [X, 1]
     OK = torch.zeros(ds.Tp, 2 * eng.ldn, dtype=torch.float64, device="cuda")
     OK[:T, :4] = W[:T]

@@ -168,3 +168,15 @@ def test_sweep_with_integer_gram_equals_fp64_sweep_and_oracle(N, B, T, batch):
         r.resample([(X[: T // 2], Y[: T // 2, n]), (X[T // 2:], Y[T // 2:, n])], [omegas[0][:, n], omegas[1][:, n]], perm[n], u[n], z[n])
         np.testing.assert_array_equal(outs[0][0][n], r.a)
         np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
+
+
+def test_auto_takes_the_integer_gram_where_it_pays():
+    """gram='auto' (the default): int8 planes for large D and long T, the fp64 kernel for small shapes and for the Gaussian model"""
+    from pyglm_amd.engine import GibbsEngine
+    rng = np.random.default_rng(0)
+    for N, B, T, obs, want in [(210, 5, 2100, "bernoulli", True), (210, 5, 1500, "bernoulli", False), (60, 3, 4000, "bernoulli", False),
+                               (210, 5, 2100, "gaussian", False)]:
+        eng = GibbsEngine(N, B, n1=4, obs=obs, batch=4)
+        ds = eng.add_data((rng.random((T, N)) < 0.1).astype(float), X=rng.random((T, N, B)) * 0.1)
+        assert eng.gram == "auto" and ds.int8 == want, (N, B, T, obs)
+        assert (eng._i8_scratch is not None) == want

@@ -130,6 +130,9 @@ def test_pushed_hyper_cache_equals_dense_terms():
     N, B = 7, 3
     m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
     m.resample_network()
+    assert type(m.regressions[0]._S_w).__name__ == "_BlockRows"           # pushed as (shared block, own block), expanded only when read
+    np.testing.assert_array_equal(m.regressions[4].S_w, m.network.sigma_W[4])
+    np.testing.assert_array_equal(m.regressions[4].mu_w, m.network.mu_W[4])
     versions, (rho, prior, _, Jb, hb, _) = m._hyper_cache
     assert prior.Jw_u.shape[0] <= 3 and prior.label.shape == (N, N)      # a handful of distinct blocks, never expanded
     Jw, hw, c0 = prior.dense()

@@ -43,7 +43,10 @@ __device__ __forceinline__ int isqrt_tri(int t) {
 // 8 = every item stages tile (0, 0) (all requests hit L2)
 // tile t of a plane's lower triangle in CLUSTERED order: super-blocks of SB x SB tiles, row by row (boustrophedon), so that any run
 // of ~32 consecutive tiles touches few distinct 256-row strips (they are shared through the XCD's L2)
-constexpr int SB = 6;
+#ifndef SB_
+#define SB_ 6
+#endif
+constexpr int SB = SB_;
 __device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn) {
     const int nsb = (ntm + SB - 1) / SB;
     for (int I = 0; I < nsb; ++I) {
@@ -324,12 +327,7 @@ static void run(int D, int K, int Q, bool check, int sustain = 0) {
 int main(int argc, char** argv) {
     if (argc > 1) {
         const int n = atoi(argv[1]);
-        run<0, true, 6>(5120, 100096, 60, false, n);
-        run<0, true, 14>(5120, 100096, 60, false, n);
         run<0, true, 22>(5120, 100096, 60, false, n);
-        run<0, true, 30>(5120, 100096, 60, false, n);
-        run<8, true, 6>(5120, 100096, 60, false, n);
-        run<1, true, 6>(5120, 100096, 60, false, n);
         return 0;
     }
     if (NST == 4) run<0, false>(512, 1024, 2, true);
