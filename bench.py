@@ -166,7 +166,12 @@ def main():
     ll = model.log_likelihood()
     # the same sampler with the Gram forced onto the fp64-MFMA kernel, one more sweep of the same chain (not part of `value`)
     cmp64 = None
-    if any(ds.int8 for ds in model.engine.datasets) and not args.no_fp64_compare:
+    took_i8 = any(ds.int8 for ds in model.engine.datasets)
+    if use_dist:      # the extra sweep contains collectives: every rank runs it, or none (a rank short of memory may have stayed on fp64)
+        t = torch.tensor([float(took_i8)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        took_i8 = bool(t.item())
+    if took_i8 and not args.no_fp64_compare:
         for ds in model.engine.datasets:
             ds.int8 = False
         model.engine.profile = True
@@ -230,11 +235,11 @@ def main():
                 except Exception:
                     tr = None
             out["dtype"] = "f64 (likelihood Gram: exact integer arithmetic on i8 residue planes, CRT back to f64)"
-            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_32x32x32_i8; 15 residue planes of %d neurons per launch)" % (model.engine._i8_scratch[2] if model.engine._i8_scratch else 0),
+            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_16x16x64_i8; 15 residue planes of %d neurons per launch)" % (model.engine._i8_scratch[2] if model.engine._i8_scratch else 0),
                                "achieved": ach, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS, "traffic": tr,
                                "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"],
                                "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,
-                               "power_limited_mfma_only_tops": 3450.0}
+                               "power_limited_mfma_only_tops": 4000.0}
             if cmp64:
                 out["fp64_gram_path"] = cmp64
         if cfg.get("obs") == "gaussian":

@@ -10,12 +10,13 @@
 //   i8_planes_kernel   fp64 (t-major) -> 15 residue planes in BLOCKED layout [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once
 //                      per data set), PB[g] for omega_g X (per neuron, per sweep); one pass over X per group of neurons; residues by four
 //                      fp64 operations each (no integer division)
-//   i8_gram_kernel     R[g][q] = (PA[q] PB[g][q]') mod p_q on lower 256 x 256 tiles (v_mfma_i32_32x32x32_i8; 8 waves = 2 x 4, wave tile
+//   i8_gram_kernel     R[g][q] = (PA[q] PB[g][q]') mod p_q on lower 256 x 256 tiles (v_mfma_i32_16x16x64_i8; 8 waves = 2 x 4, wave tile
 //                      128 x 64; K tiles DMA-staged into 4 LDS stages, one contiguous KiB per request, 16-byte chunks XOR-swizzled:
 //                      conflict-free ds_read_b128); persistent workgroups, per-XCD work lists in a clustered tile order (L2 sharing)
 //   i8_crt_kernel      15 residues -> mixed-radix digits (Garner) -> fp64 by Horner -> scaled into the lower triangle of J
 #include "pgl_common.h"
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -188,6 +189,8 @@ __device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn)
     tm = tn = 0;
 }
 
+__device__ __forceinline__ int chunk_swz(int qd) { return (0x1320 >> (4 * qd)) & 3; }     // g = {0, 2, 3, 1}
+
 __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds) {
     const int m0 = tm * TM, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,35 +203,39 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
     // DMA: per K tile 512 rows x 64 B = 32 requests of 1 KiB (16 rows = one row block of the blocked plane layout: contiguous in memory,
     // and a row block's K tiles follow each other -- with row-major planes a request was sixteen 64-byte pieces 100 KB apart and the
     // kernel was bound by the L2 -> LDS path at 2.7 POPS).  Wave w issues requests w, w+8 (A rows) and w+16, w+24 (B rows).  Lane l
-    // fills row 16 rq + l / 4, physical 16-byte chunk l % 4, with logical chunk (l % 4) ^ ((row >> 2) & 3)
+    // fills row 16 rq + l / 4, physical 16-byte chunk l % 4, with logical chunk (l % 4) ^ g((row >> 2) & 3), g = {0, 2, 3, 1}
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const char* gp[4];
     int loff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rq = wv + 8 * i;
-        const int lc = (lane & 3) ^ ((lane >> 4) & 3);
+        const int lc = (lane & 3) ^ chunk_swz((lane >> 4) & 3);
         const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.Kp : B + (long)(n0 + 16 * rq - TM) * g.Kp;
         gp[i] = reinterpret_cast<const char*>(base) + (lane >> 2) * 64 + lc * 16;
         loff[i] = rq * 1024;
     }
-    v16i acc[4][2];
+    // v_mfma_i32_16x16x64_i8: 8 x 4 accumulators of 16 x 16 per wave, ONE k-step per 64-byte K tile.  (On random operand bytes -- what
+    // residues are -- the package power limit sets the rate, and this form sustains 4.0 POP/s where v_mfma_i32_32x32x32_i8 sustains 3.45:
+    // tools/ubench_i8.hip; the kernel gained 11 % from the switch.)  A/B fragment = 16 rows x 64 B: lane l -> row l % 16, 16-byte chunk
+    // l / 16; the chunk swizzle above makes the 4 x 16 lane groups of ds_read_b128 conflict-free.
+    v4i acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-    const int fr = lane & 31, fk = lane >> 5;
-    auto frag = [&](int stage, int row, int kk) {
-        const int pc = (kk * 2 + fk) ^ ((row >> 2) & 3);
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    const int fr = lane & 15, fc = lane >> 4;
+    auto frag = [&](int stage, int row) {
+        const int pc = fc ^ chunk_swz((row >> 2) & 3);
         return *reinterpret_cast<const v4i*>(lds + stage * STAGE_BYTES + row * BKB + pc * 16);
     };
-    // Pipeline: tiles are requested NST - 1 = 3 ahead, two requests per k-step (requests 0, 1 of tile kt+3 in the second k-step of tile
-    // kt, requests 2, 3 in the first k-step of tile kt+1); fragments double-buffered in registers, every LDS read and DMA request issued
-    // in the shadow of an MFMA (order pinned with sched_barrier); the barrier sits in the MIDDLE of a K tile (after its first k-step):
-    // it publishes tile kt+1, whose first fragments are fetched during the second k-step, and frees the stage of tile kt-1.
-    // Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
+    auto rdA = [&](int stage, int f) { return frag(stage, wm * 128 + f * 16 + fr); };
+    auto rdB = [&](int stage, int f) { return frag(stage, TM + wn * 64 + f * 16 + fr); };
+    // Pipeline: tiles are requested NST - 1 = 3 ahead, two requests per half tile (requests 0, 1 of tile kt+3 in the second half of tile
+    // kt, requests 2, 3 in the first half of tile kt+1).  A tile is two halves of 16 MFMAs: A0-3 x B, then A4-7 x B.  Fragment registers:
+    // A 8, B 2 x 4: the second half prefetches the next tile's A0-3 and B, the first half fetches its own A4-7.  Every LDS read and DMA
+    // request is issued in the shadow of an MFMA (order pinned with sched_barrier); the barrier sits BETWEEN the halves: it publishes tile
+    // kt+1 and frees the stage of tile kt-1.  Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
     long gadv = 1024, gadv2 = 1024;   // 0 once the last tile has been requested: the cursors stop and the last tile is requested again
     auto dma_piece = [&](int stage, int i, long adv) {      // (into a stage nobody reads any more) -- no branch in front of a request
         __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
@@ -244,67 +251,69 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    v4i F[2][6];
-    auto rd = [&](int stage, int kk, int f) {
-        return f < 4 ? frag(stage, wm * 128 + f * 32 + fr, kk) : frag(stage, TM + wn * 64 + (f - 4) * 32 + fr, kk);
-    };
+    v4i FA[8], FB[2][4];
 #pragma unroll
-    for (int f = 0; f < 6; ++f) F[0][f] = rd(0, 0, f);
+    for (int f = 0; f < 4; ++f) { FA[f] = rdA(0, f); FB[0][f] = rdB(0, f); }
     const double pq = (double)c_mod[q], ipq = 1.0 / pq;
     auto reduce = [&](int v) {                              // symmetric representative of v mod p (exact: |v| < 2^31)
         const double x = (double)v;
         return (int)fma(-pq, rint(x * ipq), x);
     };
     int cur = 0;
-    for (int kc = 0; kc < nkt; kc += KCH) {
-        const int kend = min(nkt, kc + KCH);
-        for (int kt = kc; kt < kend; ++kt) {
-            const int nxt = cur == NST - 1 ? 0 : cur + 1;
-            const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes the first half of tile kt+3
-            const int dst2 = cur ^ 2;                               // the stage of tile kt-2 takes the second half of tile kt+2
-            if (kt + NST >= nkt) gadv = 0;
-            if (kt + NST - 1 >= nkt) gadv2 = 0;
-            // ---- first k-step (set 0): prefetch the fragments of this tile's second k-step
+    auto tile = [&](auto pb_c, const int kt) {               // PB: which B buffer this tile multiplies with (compile-time index)
+        constexpr int PB = decltype(pb_c)::value;
+        const int nxt = cur == NST - 1 ? 0 : cur + 1;
+        const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes the first half of tile kt+3
+        const int dst2 = cur ^ 2;                               // the stage of tile kt-2 takes the second half of tile kt+2
+        if (kt + NST >= nkt) gadv = 0;
+        if (kt + NST - 1 >= nkt) gadv2 = 0;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0][m >> 1], F[0][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
-                if (m < 6) F[1][m] = rd(cur, 1, m);
-                if (m == 3 || m == 7) dma_piece(dst2, 2 + (m >> 2), gadv2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // ---- second k-step (set 1): prefetch the first fragments of tile kt+1
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[1][m >> 1], F[1][4 + (m & 1)], acc[m >> 1][m & 1], 0, 0, 0);
-                if (m < 6) F[0][m] = rd(nxt, 0, m);
-                if (m == 3 || m == 7) dma_piece(dst, m >> 2, gadv);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            cur = nxt;
+        for (int m = 0; m < 16; ++m) {
+            const int ai = m >> 2, bj = m & 3;
+            acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
+            if (m < 4) FA[4 + m] = rdA(cur, 4 + m);
+            if (m == 7 || m == 15) dma_piece(dst2, 2 + (m >> 3), gadv2);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int ai = 4 + (m >> 2), bj = m & 3;
+            acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
+            if (m < 4) FB[PB ^ 1][m] = rdB(nxt, m);
+            else if (m < 8) FA[m - 4] = rdA(nxt, m - 4);
+            if (m == 7 || m == 15) dma_piece(dst, m >> 3, gadv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
+    };
+    for (int kc = 0; kc < nkt; kc += KCH) {                 // KCH is even: every chunk starts on B buffer 0
+        const int kend = min(nkt, kc + KCH);
+        int kt = kc;
+        for (; kt + 1 < kend; kt += 2) { tile(std::integral_constant<int, 0>{}, kt); tile(std::integral_constant<int, 1>{}, kt + 1); }
+        if (kt < kend) tile(std::integral_constant<int, 0>{}, kt);        // only the very last tile of an odd total
         if (kend < nkt) {                                           // long data sets: bring the int32 sums back below p before they can overflow
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = reduce(acc[i][j][r]);
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = reduce(acc[i][j][r]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant last requests must have landed before the LDS is reused
-    // epilogue: reduce mod p and store bytes.  C/D layout of 32x32 i32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // epilogue: reduce mod p and store bytes.  C/D layout of 16x16 i32: col = lane & 15, row = 4 (lane >> 4) + reg
     int8_t* R = g.R + ((long)gz * NP + q) * g.Dq * g.Dq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
+                const int col = n0 + wn * 64 + j * 16 + (lane & 15);
                 R[(long)row * g.Dq + col] = (int8_t)(reduce(acc[i][j][r]) & 0xff);   // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
             }
 }

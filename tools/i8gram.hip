@@ -210,6 +210,111 @@ __device__ __forceinline__ void i8gram_item(const Args& g, const int q, const in
             }
 }
 
+// ---- the same item on v_mfma_i32_16x16x64_i8 (VAR & 32): 8 x 4 accumulators of 16 x 16 per wave, ONE k-step per 64-byte K tile.  On random
+// operand bytes this instruction sustains 4.0 POP/s at the package power limit where the 32x32x32 form sustains 3.45 (tools/ubench_i8.hip).
+// A/B fragment of 16 rows x 64 B: lane l -> row l % 16, 16-byte chunk l / 16.  Chunk swizzle c ^ g(row >> 2 & 3), g = {0, 2, 3, 1}:
+// conflict-free for the 4 x 16 lane groups of ds_read_b128.  Fragment registers: A 8, B 2 x 4 (double-buffered): the second half of a
+// tile (A4-7) prefetches the next tile's A0-3 and B, the first half (A0-3) fetches its own A4-7.
+template <int ABL, int VAR>
+__device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const int tm, const int tn, char* lds) {
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int8_t* A = g.A + (long)q * g.D * g.ldk;
+    const int8_t* B = g.B + (long)q * g.D * g.ldk;
+    const int nkt = g.K / BKB;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto gsw = [](int qd) { return (0x1320 >> (4 * qd)) & 3; };          // g = {0, 2, 3, 1}
+    const char* gp[4];
+    int loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rq = wv + 8 * i;
+        const int lc = (lane & 3) ^ gsw((lane >> 4) & 3);
+        const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.ldk : B + (long)(n0 + 16 * rq - TM) * g.ldk;
+        gp[i] = reinterpret_cast<const char*>(base) + (lane >> 2) * 64 + lc * 16;
+        loff[i] = rq * 1024;
+    }
+    v4i acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    const int fr = lane & 15, fc = lane >> 4;
+    auto frag = [&](int stage, int row) {
+        const int pc = fc ^ gsw((row >> 2) & 3);
+        return *reinterpret_cast<const v4i*>(lds + stage * STAGE_BYTES + row * BKB + pc * 16);
+    };
+    auto rdA = [&](int stage, int f) { return frag(stage, wm * 128 + f * 16 + fr); };
+    auto rdB = [&](int stage, int f) { return frag(stage, TM + wn * 64 + f * 16 + fr); };
+    long gadv = 1024, gadv2 = 1024;
+    auto dma_piece = [&](int stage, int i, long adv) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
+        gp[i] += adv;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(0, i, 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(1, i, 1024);
+    dma_piece(2, 0, 1024);
+    dma_piece(2, 1, 1024);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    v4i FA[8], FB[2][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { FA[f] = rdA(0, f); FB[0][f] = rdB(0, f); }
+    int cur = 0;
+    // two tiles per iteration so that the B buffers alternate with compile-time indices
+    auto tile = [&](auto pb_c, const int kt) {
+        constexpr int PB = decltype(pb_c)::value;
+        const int nxt = cur == NST - 1 ? 0 : cur + 1;
+        const int dst = cur == 0 ? NST - 1 : cur - 1;
+        const int dst2 = cur ^ 2;
+        if (kt + NST >= nkt) gadv = 0;
+        if (kt + NST - 1 >= nkt) gadv2 = 0;
+        // ---- first half: A0-3 x B; fetch this tile's A4-7
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int ai = m >> 2, bj = m & 3;
+            acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
+            if (m < 4) FA[4 + m] = rdA(cur, 4 + m);
+            if (m == 7 || m == 15) dma_piece(dst2, 2 + (m >> 3), gadv2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- second half: A4-7 x B; prefetch the next tile's A0-3 and B
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int ai = 4 + (m >> 2), bj = m & 3;
+            acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
+            if (m < 4) FB[PB ^ 1][m] = rdB(nxt, m);
+            else if (m < 8) FA[m - 4] = rdA(nxt, m - 4);
+            if (m == 7 || m == 15) dma_piece(dst, m >> 3, gadv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
+    };
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) { tile(std::integral_constant<int, 0>{}, kt); tile(std::integral_constant<int, 1>{}, kt + 1); }
+    if (kt < nkt) tile(std::integral_constant<int, 0>{}, kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue: C/D layout of 16x16 i32: col = lane & 15, row = 4 (lane >> 4) + reg
+    int32_t* C = g.C + (long)q * g.D * g.D;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
+                const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+                C[(long)row * g.D + col] = acc[i][j][r];
+            }
+}
+
 template <int ABL, int VAR>
 __global__ __launch_bounds__(512) void i8gram_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -253,7 +358,7 @@ __global__ __launch_bounds__(512) void i8gram_persistent(Args g, int* sched) {
         __syncthreads();
         if (ticket[0] < 0) break;
         const int q = __builtin_amdgcn_readfirstlane(ticket[1]), tm = __builtin_amdgcn_readfirstlane(ticket[2]), tn = __builtin_amdgcn_readfirstlane(ticket[3]);
-        i8gram_item<ABL, VAR>(g, q, tm, tn, lds);
+        if constexpr ((VAR & 32) != 0) i8gram_item16<ABL, VAR>(g, q, tm, tn, lds); else i8gram_item<ABL, VAR>(g, q, tm, tn, lds);
     }
 }
 
@@ -327,13 +432,13 @@ static void run(int D, int K, int Q, bool check, int sustain = 0) {
 int main(int argc, char** argv) {
     if (argc > 1) {
         const int n = atoi(argv[1]);
-        run<0, true, 22>(5120, 100096, 60, false, n);
+        run<0, true, 6>(5120, 100096, 60, false, n);
+        run<0, true, 38>(5120, 100096, 60, false, n);
         return 0;
     }
-    if (NST == 4) run<0, false>(512, 1024, 2, true);
-    run<0, true, 7>(3584, 512, 2, true);
     run<0, true, 6>(3584, 320, 2, true);
-    run<0, true, 30>(3584, 320, 2, true);
-    run<0, true, 6>(5120, 100096, 60, false);
+    run<0, true, 38>(3584, 320, 2, true);
+    run<0, true, 38>(1024, 384, 3, true);
+    run<0, true, 38>(5120, 100096, 60, false);
     return 0;
 }

@@ -33,6 +33,29 @@ __global__ __launch_bounds__(THR) void k_reg(int* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the same with v_mfma_i32_16x16x64_i8 (4 accumulator registers per 16 x 16 block): TM x TN blocks of 16 x 16
+template <int TM, int TN, int THR>
+__global__ __launch_bounds__(THR) void k_reg16(int* out, int iters) {
+    v4i acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    v4i a[TM], b[TN];
+    unsigned h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+    auto nx = [&] { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (int)h; };
+    const bool rnd = iters < 0;
+    if (rnd) iters = -iters;
+    for (int i = 0; i < TM; ++i) a[i] = rnd ? v4i{nx(), nx(), nx(), nx()} : v4i{(int)threadIdx.x, i, 3, 4};
+    for (int j = 0; j < TN; ++j) b[j] = rnd ? v4i{nx(), nx(), nx(), nx()} : v4i{j, (int)threadIdx.x * 7, 1, 2};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    int s = 0;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // LDS-fed: every wave owns a [TM*32 + TN*32][BKB + PAD] byte region (or shares one: SHARE) and sweeps it repeatedly
 template <int TM, int TN, int BKB, int PAD, bool SHARE, int THR>
 __global__ __launch_bounds__(THR) void k_lds(int* out, int iters) {
@@ -83,6 +106,12 @@ int main(int argc, char** argv) {
     const double mfma_ops = 32.0 * 32 * 32 * 2;
     if (argc > 1) {     // sustained register-only rate: argv[1] = +1 constant operands, -1 random operands; ~6 s
         const int sgn = atoi(argv[1]);
+        if (argc > 2) {   // 16x16x64 variant, 8 x 4 blocks (the same 128 x 64 wave tile)
+            for (int rep = 0; rep < 8; ++rep)
+                timeit(sgn < 0 ? "reg16 8x4 512 thr/CU, random operands, sustained" : "reg16 8x4 512 thr/CU, constant operands, sustained",
+                       (double)cus * 8 * 2000000.0 * 32 * (16.0 * 16 * 64 * 2), [&] { k_reg16<8, 4, 512><<<cus, 512>>>(out, sgn * 2000000); });
+            return 0;
+        }
         for (int rep = 0; rep < 12; ++rep)
             timeit(sgn < 0 ? "reg 4x2 512 thr/CU, random operands, sustained" : "reg 4x2 512 thr/CU, constant operands, sustained", (double)cus * 8 * 4000000.0 * 8 * mfma_ops,
                    [&] { k_reg<4, 2, 512><<<cus, 512>>>(out, sgn * 4000000); });
