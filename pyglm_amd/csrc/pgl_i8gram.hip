@@ -25,16 +25,19 @@ constexpr int NP = 15;
 // 256 comes first: its residue is the low byte, and as the least significant mixed-radix digit its two representations of 128 are harmless
 struct ModTable {
     int p[NP] = {256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197};
-    int inv[NP][NP] = {};             // inv[j][i] = p_j^-1 mod p_i
+    int w[NP][NP] = {};               // w[k][q] = (p_0 ... p_{k-1}) mod p_q, symmetric representative (k < q)
+    int pinv[NP] = {};                // pinv[q] = (p_0 ... p_{q-1})^-1 mod p_q
     constexpr ModTable() {
-        for (int j = 0; j < NP; ++j)
-            for (int i = 0; i < NP; ++i) {
-                if (i == j) continue;
-                const int a = p[j] % p[i];
-                int x = 1;
-                while ((a * x) % p[i] != 1) ++x;
-                inv[j][i] = x;
+        for (int q = 1; q < NP; ++q) {
+            int prod = 1;
+            for (int k = 0; k < q; ++k) {
+                w[k][q] = prod > p[q] / 2 ? prod - p[q] : prod;
+                prod = (prod * (p[k] % p[q])) % p[q];
             }
+            int x = 1;
+            while ((prod * x) % p[q] != 1) ++x;
+            pinv[q] = x;
+        }
     }
 };
 constexpr ModTable MT{};
@@ -370,13 +373,16 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
     int v[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) v[q] = (int)R[(long)q * a.Dq * a.Dq];
-    // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...
+    // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...;  digit q =
+    // (r_q - sum_{k<q} v_k (p_0..p_{k-1} mod p_q)) (p_0..p_{q-1})^-1 mod p_q: the sum is accumulated unreduced (14 terms of at most
+    // 128 * 128), so a digit costs q multiply-adds and ONE reduction instead of q reductions
 #pragma unroll
     for (int q = 1; q < NP; ++q) {
         const int p = MT.p[q];
-        int t = v[q];
+        int u = v[q];
 #pragma unroll
-        for (int r = 0; r < q; ++r) t = (t - v[r]) * MT.inv[r][q] % p;                // |t - v| < 2^9, inverse < 2^8: no overflow
+        for (int k = 0; k < q; ++k) u -= v[k] * MT.w[k][q];                          // |u| < 2^18
+        int t = u * MT.pinv[q] % p;                                                   // < 2^26 in magnitude
         if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
         v[q] = t;
     }
