@@ -61,12 +61,15 @@ __global__ __launch_bounds__(256) void colmax_kernel(const double* __restrict__ 
     __shared__ double red[4][64];
     double m = 0.0;
     if (c < ncol)
-        for (int t = blockIdx.y * 4 + part; t < T; t += gridDim.y * 4) m = fmax(m, fabs(V[(long)t * ldv + c]));
+        for (int t = blockIdx.y * 4 + part; t < T; t += gridDim.y * 4) {
+            const double v = fabs(V[(long)t * ldv + c]);
+            m = v > m || v != v ? v : m;                 // a NaN sticks (fmax would drop it): the Gram of that column is then NaN, as in fp64
+        }
     red[part][threadIdx.x & 63] = m;
     __syncthreads();
     if (part == 0 && c < ncol) {
-        m = fmax(fmax(red[0][threadIdx.x], red[1][threadIdx.x]), fmax(red[2][threadIdx.x], red[3][threadIdx.x]));
-        // non-negative doubles order like their bit patterns
+        for (int k = 1; k < 4; ++k) { const double v = red[k][threadIdx.x]; m = v > m || v != v ? v : m; }
+        // non-negative doubles order like their bit patterns (+inf and NaN above every finite value)
         atomicMax(reinterpret_cast<unsigned long long*>(out + c), (unsigned long long)__double_as_longlong(m));
     }
 }
@@ -390,7 +393,9 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
 #pragma unroll
     for (int q = NP - 2; q >= 0; --q) s = s * (double)MT.p[q] + (double)v[q];
     const int e = scale_exp(a.xmax[i], a.beta) + scale_exp(a.wmax[gz] * a.xmax[j], a.beta);
-    const double val = ldexp(s, -e);
+    // non-finite data (a diverged chain): NaN out, as the fp64 product would give -- never a finite number made of garbage residues
+    const bool finite = a.xmax[i] < HUGE_VAL && a.xmax[j] < HUGE_VAL && a.wmax[gz] < HUGE_VAL;
+    const double val = finite ? ldexp(s, -e) : __builtin_nan("");
     double* dst = a.J + (long)gz * a.strideJ + (long)i * a.ldj + j;
     *dst = a.accumulate ? *dst + val : val;
 }

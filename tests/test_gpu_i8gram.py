@@ -180,3 +180,33 @@ def test_auto_takes_the_integer_gram_where_it_pays():
         ds = eng.add_data((rng.random((T, N)) < 0.1).astype(float), X=rng.random((T, N, B)) * 0.1)
         assert eng.gram == "auto" and ds.int8 == want, (N, B, T, obs)
         assert (eng._i8_scratch is not None) == want
+
+
+def test_non_finite_weights_give_nan_not_garbage():
+    """a NaN / inf in a neuron's omega (a diverged chain) must surface as NaN in that neuron's Gram, as it does on the fp64 kernel"""
+    import torch
+    from pyglm_amd._lib import call, ptr, load
+    T, D, G = 700, 40, 3
+    X, Om, Xd, Od, xmax, wmax = _setup(T, D, G, seed=5)
+    Od[123, 1] = float("nan")
+    Od[55, 2] = float("inf")
+    wmax.zero_()
+    call("pgl_i8_colmax", ptr(Od), G, T, G, ptr(wmax), None)
+    lib = load()
+    dev = "cuda:0"
+    PA = torch.empty(lib.pgl_i8_plane_bytes(D, T), dtype=torch.int8, device=dev)
+    PB = torch.empty(G * lib.pgl_i8_plane_bytes(D, T), dtype=torch.int8, device=dev)
+    R = torch.empty(G * lib.pgl_i8_residue_bytes(D), dtype=torch.int8, device=dev)
+    ldj = (D + 2 + 15) // 16 * 16
+    J = torch.zeros(G, ldj, ldj, dtype=torch.float64, device=dev)
+    call("pgl_i8_planes", ptr(Xd), D, None, 0, ptr(xmax), None, ptr(PA), T, D, 1, None)
+    call("pgl_i8_planes", ptr(Xd), D, ptr(Od), G, ptr(xmax), ptr(wmax), ptr(PB), T, D, G, None)
+    call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), T, D, G, None)
+    call("pgl_i8_crt", ptr(R), ptr(xmax), ptr(wmax), ptr(J), ldj, ldj * ldj, T, D, G, 0, None)
+    torch.cuda.synchronize()
+    Jh = J.cpu().numpy()
+    low = np.tril(np.ones((D, D), dtype=bool))
+    assert np.isfinite(Jh[0, :D, :D][low]).all()
+    assert np.isnan(Jh[1, :D, :D][low]).all() and np.isnan(Jh[2, :D, :D][low]).all()
+    ref = (X * Om[:, 0:1]).T @ X
+    np.testing.assert_allclose(Jh[0, :D, :D][low], ref[low], rtol=1e-11, atol=1e-13 * np.abs(ref).max())
