@@ -107,12 +107,14 @@ def _hyp(reg_list):
     return (rho,) + prior_terms(S_w, mu_w, S_b, mu_b)
 
 
+@pytest.mark.parametrize("gram", ["fp64", "int8"])
 @pytest.mark.parametrize("tag", ["c0", "c1", "c2", "c3"])
-def test_regression_resample_golden(torch_dev, golden, tag):
+def test_regression_resample_golden(torch_dev, golden, tag, gram):
+    """the reference's own vectors (tests/golden), with the likelihood Gram on the fp64 kernel and as integer arithmetic on the int8 MFMA"""
     g = golden
     N, B = g[tag + "_mu_w"].shape
     r = orc.Regression(N, B, rho=g[tag + "_rho"], mu_w=g[tag + "_mu_w"], S_w=g[tag + "_S_w"], mu_b=g[tag + "_mu_b"], S_b=g[tag + "_S_b"])
-    eng = _engine(N, B, 0, 1)
+    eng = _engine(N, B, 0, 1, gram=gram)
     datas = [(g[tag + "_X"], g[tag + "_y"]), (g[tag + "_X2"], g[tag + "_y2"])]
     for X, y in datas:
         Y = np.zeros((len(y), N))
@@ -137,10 +139,11 @@ def test_regression_resample_golden(torch_dev, golden, tag):
     np.testing.assert_allclose(b1, g[tag + "_b1"], rtol=1e-8, atol=1e-10)
 
 
-def test_model_sweep_golden(torch_dev, golden):
+@pytest.mark.parametrize("gram", ["fp64", "int8"])
+def test_model_sweep_golden(torch_dev, golden, gram):
     g = golden
     N, _, B = g["M_W0"].shape
-    eng = _engine(N, B, batch=3)                   # 4 neurons in batches of 3 + 1
+    eng = _engine(N, B, batch=3, gram=gram)        # 4 neurons in batches of 3 + 1
     eng.add_data(g["M_Y"], basis=g["M_basis"])
     np.testing.assert_allclose(eng.design_matrix(), g["M_X"], rtol=1e-10, atol=1e-13)
     ll0 = eng.log_likelihood(g["M_A0"], g["M_W0"], g["M_b0"])
@@ -275,8 +278,10 @@ def test_visit_order_and_plain_tableau_agree(torch_dev):
         np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
 
 
-def test_sharded_equals_unsharded(torch_dev):
-    """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit"""
+@pytest.mark.parametrize("gram", ["fp64", "int8"])
+def test_sharded_equals_unsharded(torch_dev, gram):
+    """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit (with the fp64 Gram and
+    with the integer Gram, whose neurons travel in groups: scales, planes and residues are per neuron, so the grouping cannot matter)"""
     from pyglm_amd.engine import make_draws
     N, B, T = 11, 2, 600
     basis, X, Y, rng = _random_problem(N, B, T, seed=5)
@@ -288,7 +293,7 @@ def test_sharded_equals_unsharded(torch_dev):
     hyp = _hyp(regs)
     res = {}
     for (lo, hi) in [(0, N), (0, 5), (5, N)]:
-        eng = _engine(N, B, lo, hi)
+        eng = _engine(N, B, lo, hi, gram=gram)
         eng.add_data(Y, basis=basis)
         perm, u, z = make_draws(9, 2, range(lo, hi), N, N * B)
         sl = slice(lo, hi)
