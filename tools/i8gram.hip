@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -231,7 +232,7 @@ __device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const 
     for (int i = 0; i < 4; ++i) {
         const int rq = wv + 8 * i;
         const int lc = (lane & 3) ^ gsw((lane >> 4) & 3);
-        const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.ldk : B + (long)(n0 + 16 * rq - TM) * g.ldk;
+        const int8_t* base = (ABL & 8) ? (i < 2 ? A + (long)(16 * rq) * g.ldk : B + (long)(16 * rq - TM) * g.ldk) : (i < 2 ? A + (long)(m0 + 16 * rq) * g.ldk : B + (long)(n0 + 16 * rq - TM) * g.ldk);
         gp[i] = reinterpret_cast<const char*>(base) + (lane >> 2) * 64 + lc * 16;
         loff[i] = rq * 1024;
     }
@@ -264,6 +265,9 @@ __device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const 
     v4i FA[8], FB[2][4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { FA[f] = rdA(0, f); FB[0][f] = rdB(0, f); }
+    if (ABL & 4)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { FA[4 + f] = rdA(0, 4 + f); FB[1][f] = rdB(1, f); }
     int cur = 0;
     // two tiles per iteration so that the B buffers alternate with compile-time indices
     // VAR & 64: on a diagonal tile the 16 x 16 blocks that lie entirely above the diagonal are not multiplied (47 % of such a tile)
@@ -287,8 +291,8 @@ __device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const 
         for (int m = 0; m < 16; ++m) {
             const int ai = m >> 2, bj = m & 3;
             if (!DG || !((skip1 >> m) & 1)) acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
-            if (m < 4) FA[4 + m] = rdA(cur, 4 + m);
-            if (m == 7 || m == 15) dma_piece(dst2, 2 + (m >> 3), gadv2);
+            if (m < 4 && !(ABL & 4)) FA[4 + m] = rdA(cur, 4 + m);
+            if ((m == 7 || m == 15) && !(ABL & 1)) dma_piece(dst2, 2 + (m >> 3), gadv2);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -299,9 +303,9 @@ __device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const 
         for (int m = 0; m < 16; ++m) {
             const int ai = 4 + (m >> 2), bj = m & 3;
             if (!DG || !((skip2 >> m) & 1)) acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
-            if (m < 4) FB[PB ^ 1][m] = rdB(nxt, m);
-            else if (m < 8) FA[m - 4] = rdA(nxt, m - 4);
-            if (m == 7 || m == 15) dma_piece(dst, m >> 3, gadv);
+            if (m < 4 && !(ABL & 4)) FB[PB ^ 1][m] = rdB(nxt, m);
+            else if (m < 8 && !(ABL & 4)) FA[m - 4] = rdA(nxt, m - 4);
+            if ((m == 7 || m == 15) && !(ABL & 1)) dma_piece(dst, m >> 3, gadv);
             __builtin_amdgcn_sched_barrier(0);
         }
         cur = nxt;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(512) void i8gram_kernel(Args g) {
 // belongs to XCD c % 8, so the workgroups of an XCD work through one chunk together.
 constexpr int CH = 32;
 template <int ABL, int VAR>
-__global__ __launch_bounds__(512) void i8gram_persistent(Args g, int* sched) {
+__global__ __launch_bounds__(512) void i8gram_persistent(Args g, int* sched, const int* lists, const int* lens, int maxlen) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int* ticket = reinterpret_cast<int*>(lds + (NST == 5 ? LDS_BYTES - 16 : LDS_BYTES));   // 5 stages fill the LDS: the ticket borrows the tail of the last stage between items
     const int ntm = g.D / TM;
@@ -356,13 +360,18 @@ __global__ __launch_bounds__(512) void i8gram_persistent(Args g, int* sched) {
         __syncthreads();
         if (threadIdx.x == 0) {
             int w = -1;
+            int packed = -1;
             for (int hop = 0; hop < 8 && w < 0; ++hop) {
                 const int y = (int)((xcc + hop) & 7u);
                 const int it = atomicAdd(&sched[y], 1);
-                const int c = (it / CH) * 8 + y, cand = c * CH + it % CH;
-                if (cand < total) w = cand;
+                if constexpr ((VAR & 128) != 0) { if (it < lens[y]) { packed = lists[(long)y * maxlen + it]; w = 1; } }
+                else {
+                    const int c = (it / CH) * 8 + y, cand = c * CH + it % CH;
+                    if (cand < total) w = cand;
+                }
             }
-            if (w >= 0) {
+            if ((VAR & 128) && w >= 0) { ticket[1] = packed >> 16; ticket[2] = (packed >> 8) & 255; ticket[3] = packed & 255; }
+            else if (w >= 0) {
                 int tm, tn;
                 clustered_tile(w % ntiles, ntm, tm, tn);
                 ticket[1] = w / ntiles; ticket[2] = tm; ticket[3] = tn;
@@ -402,8 +411,25 @@ static void run(int D, int K, int Q, bool check, int sustain = 0) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(i8gram_kernel<ABL, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(i8gram_persistent<ABL, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS));
     int* sched; CK(hipMalloc(&sched, 64));
+    // VAR & 128: host-built per-XCD item lists: row groups of RG tile rows, swept column by column (4 tiles per column), so that any 32
+    // consecutive items of a list touch RG + ~8 distinct strips; row group r of the whole launch belongs to XCD r % 8
+    std::vector<std::vector<int>> L(8);
+    {
+        const int RG = getenv("RG") ? atoi(getenv("RG")) : 4;
+        int r = 0;
+        for (int q = 0; q < Q; ++q)
+            for (int r0 = 0; r0 < ntm; r0 += RG, ++r)
+                for (int tn = 0; tn < std::min(ntm, r0 + RG); ++tn)
+                    for (int tm = std::max(tn, r0); tm < std::min(ntm, r0 + RG); ++tm) L[r % 8].push_back(q << 16 | tm << 8 | tn);
+    }
+    int maxlen = 0, hl[8];
+    for (int y = 0; y < 8; ++y) { hl[y] = (int)L[y].size(); maxlen = std::max(maxlen, hl[y]); }
+    int *dlists, *dlens;
+    CK(hipMalloc(&dlists, (size_t)8 * maxlen * 4 + 4)); CK(hipMalloc(&dlens, 32));
+    for (int y = 0; y < 8; ++y) CK(hipMemcpy(dlists + (size_t)y * maxlen, L[y].data(), L[y].size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dlens, hl, 32, hipMemcpyHostToDevice));
     auto launch = [&] {
-        if (PERS) { CK(hipMemsetAsync(sched, 0, 32)); i8gram_persistent<ABL, VAR><<<256, 512, PLDS>>>(g, sched); }
+        if (PERS) { CK(hipMemsetAsync(sched, 0, 32)); i8gram_persistent<ABL, VAR><<<256, 512, PLDS>>>(g, sched, dlists, dlens, maxlen); }
         else i8gram_kernel<ABL, VAR><<<ntiles * Q, 512, LDS_BYTES>>>(g);
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -444,13 +470,18 @@ static void run(int D, int K, int Q, bool check, int sustain = 0) {
 }
 
 int main(int argc, char** argv) {
+    // VAR bits: 1 scalar-base requests, 2 requests spread over both k-steps, 4 blocked plane layout, 8 snake MFMA order, 16 dead wave tiles of
+    // diagonal tiles skipped, 32 v_mfma_i32_16x16x64_i8 pipeline (what the library runs), 64 16x16 blocks above the diagonal skipped,
+    // 128 host-built per-XCD item lists (row groups of RG tile rows);  ABL bits: see i8gram_item.   argv[1] = n: n x 20 sustained launches
     if (argc > 1) {
         const int n = atoi(argv[1]);
         run<0, true, 38>(5120, 100096, 60, false, n);
-        run<0, true, 102>(5120, 100096, 60, false, n);
         return 0;
     }
-    run<0, true, 102>(3584, 320, 2, true);
-    run<0, true, 102>(1024, 384, 3, true);
+    run<0, true, 6>(3584, 320, 2, true);
+    run<0, true, 38>(3584, 320, 2, true);
+    run<0, true, 38>(1024, 384, 3, true);
+    run<0, true, 166>(3584, 320, 2, true);
+    run<0, true, 38>(5120, 100096, 60, false);
     return 0;
 }
