@@ -144,7 +144,7 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
     return pgl_k_assemble_post(J, ldj, strideJ, border_omega, border_kappa, ldb, Jw, hw, label, Jb, hb, nb, N, B, ST(st));
 }
 
-// ---- integer-MFMA Gram (opt-in alternative to pgl_weighted_gram)
+// ---- integer-MFMA Gram (what the engine uses at large shapes instead of pgl_weighted_gram)
 size_t pgl_i8_plane_bytes(int D, int T) { return pgl_k_i8_plane_bytes(D, T); }
 size_t pgl_i8_residue_bytes(int D) { return pgl_k_i8_residue_bytes(D); }
 int pgl_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, void* st) {

@@ -1,5 +1,5 @@
-// The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (an OPT-IN alternative to the fp64
-// kernel of pgl_gemm.hip).  The fp64 operands are scaled column by column to beta-bit integers (beta = 50 up to
+// The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (the engine's choice at large shapes,
+// the fp64 kernel of pgl_gemm.hip otherwise).  The fp64 operands are scaled column by column to beta-bit integers (beta = 50 up to
 // T = 112 000 time bins, 49 beyond),
 //     A[t][i] = rint(x_ti 2^eA_i),      B_n[t][j] = rint(omega_nt x_tj 2^fB_nj),
 // the integer Gram S = A'B_n is computed modulo 15 pairwise coprime moduli p <= 256 -- one int8 GEMM per modulus on residues that fit
