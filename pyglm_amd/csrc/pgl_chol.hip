@@ -100,41 +100,102 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(CholArgs g, int q0) {
     for (int e = tid; e < NBC * NBC; e += 256) { const int k = e / NBC, m = e % NBC; Tn[e] = Li[m][k]; }
 }
 
-// one workgroup per neuron:  U'w = h (forward, axpy form), U mu = w and U x = z (backward, dot form); scatter mu + x
+// one workgroup per neuron:  U'w = h, then U mu = w and U x = z; scatter mu + x.  Blocked by 64 rows: the 64 x 64 diagonal block is solved
+// by one wave out of LDS (the unknowns live one per lane, a step is a shuffle and one multiply-add), the rest of the 64-row panel is
+// streamed once -- forward as a column-parallel update of the remaining right-hand side, backward as row dot products over 64 x 64
+// tiles staged through LDS, one tile per wave -- with two workgroup barriers per panel instead of two per row.
 __global__ __launch_bounds__(256) void solve_sample_kernel(CholArgs g) {
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int na = g.na[n];
     const double* U = g.Ac + (long)n * g.strideC;
+    const long ld = g.ldc;
     double* h = g.hc + (long)n * g.ldc;            // becomes w, then mu
     double* xz = h + (long)gridDim.x * g.ldc;      // second plane of hc: z -> x
     const double* z = g.z + (long)n * g.ldz;
-    __shared__ double red[4];
+    __shared__ double Ud[NBC][NBC + 1];            // diagonal block
+    __shared__ double wp[2][NBC];                  // the panel's solved unknowns (two right-hand sides backward)
+    __shared__ double tile[4][NBC / 2][NBC + 1];   // backward: 32 x 64 half tiles of the panel, one per wave at a time
+    __shared__ double part[4][2][NBC];
     for (int i = tid; i < na; i += 256) xz[i] = z[i];
     __syncthreads();
-    // forward: for each row j: w_j = h_j / U_jj; h[j+1:] -= U[j][j+1:] * w_j
-    for (int j = 0; j < na; ++j) {
-        const double wj = h[j] / U[(long)j * g.ldc + j];
+    // ---- forward  U'w = h: panel p0: solve the diagonal block (w_j = h_j / U_jj; h_c -= U_jc w_j), then h[c] -= sum_j U[p0+j][c] w_j for c beyond
+    for (int p0 = 0; p0 < na; p0 += NBC) {
+        const int pw = min(NBC, na - p0);
+        for (int e = tid; e < NBC * NBC; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            Ud[r][c] = (r < pw && c < pw && c >= r) ? U[(long)(p0 + r) * ld + p0 + c] : (r == c ? 1.0 : 0.0);
+        }
         __syncthreads();
-        if (tid == 0) h[j] = wj;
-        for (int c = j + 1 + tid; c < na; c += 256) h[c] -= U[(long)j * g.ldc + c] * wj;
+        if (wave == 0) {
+            double v = lane < pw ? h[p0 + lane] : 0.0;
+            for (int j = 0; j < pw; ++j) {
+                const double wj = __shfl(v, j) / Ud[j][j];
+                if (lane == j) v = wj; else if (lane > j) v -= Ud[j][lane] * wj;
+            }
+            wp[0][lane] = v;
+            if (lane < pw) h[p0 + lane] = v;
+        }
         __syncthreads();
-    }
-    // backward (two right-hand sides at once)
-    for (int i = na - 1; i >= 0; --i) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int c = i + 1 + tid; c < na; c += 256) { const double uic = U[(long)i * g.ldc + c]; s1 += uic * h[c]; s2 += uic * xz[c]; }
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
-        __shared__ double r1[4], r2[4];
-        if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
-        __syncthreads();
-        if (tid == 0) {
-            const double d = U[(long)i * g.ldc + i];
-            h[i] = (h[i] - ((r1[0] + r1[1]) + (r1[2] + r1[3]))) / d;
-            xz[i] = (xz[i] - ((r2[0] + r2[1]) + (r2[2] + r2[3]))) / d;
+        // 32 independent row loads per column in flight (the kernel has four waves per CU: latency is hidden by depth, not by occupancy);
+        // rows past the end of a short last panel are clamped and meet wp = 0
+        for (int c = p0 + pw + tid; c < na; c += 256) {
+            double acc = 0.0;
+#pragma unroll
+            for (int jb = 0; jb < NBC; jb += 32) {
+                double u[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) u[j] = U[(long)min(p0 + jb + j, na - 1) * ld + c];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) acc += u[j] * wp[0][jb + j];
+            }
+            h[c] -= acc;
         }
         __syncthreads();
     }
-    (void)red;
+    // ---- backward  U mu = w, U x = z (two right-hand sides): panels from the last; s_r = sum_{c beyond the panel} U[r][c] v[c] by tiles
+    const int np = (na + NBC - 1) / NBC;
+    for (int pi = np - 1; pi >= 0; --pi) {
+        const int p0 = pi * NBC, pw = min(NBC, na - p0);
+        double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;   // lane r < 32 of every wave: partial sums of rows p0 + r and p0 + 32 + r
+        for (int c0 = p0 + NBC + wave * NBC; c0 < na; c0 += 4 * NBC) {
+            const int cw = min(NBC, na - c0);
+            const double v1 = lane < cw ? h[c0 + lane] : 0.0, v2 = lane < cw ? xz[c0 + lane] : 0.0;
+#pragma unroll
+            for (int rh = 0; rh < NBC; rh += NBC / 2) {
+                for (int r = 0; r < NBC / 2; ++r)
+                    tile[wave][r][lane] = (rh + r < pw && lane < cw) ? U[(long)(p0 + rh + r) * ld + c0 + lane] : 0.0;   // coalesced rows
+                __builtin_amdgcn_wave_barrier();        // one wave = one instruction stream: its LDS writes are visible to its reads
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll 8
+                for (int c = 0; c < NBC; ++c) {
+                    const double u = tile[wave][lane & 31][c];
+                    t1 += u * __shfl(v1, c);
+                    t2 += u * __shfl(v2, c);
+                }
+                if (rh == 0) { sa1 += t1; sa2 += t2; } else { sb1 += t1; sb2 += t2; }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane < 32) {
+            part[wave][0][lane] = sa1; part[wave][1][lane] = sa2;
+            part[wave][0][32 + lane] = sb1; part[wave][1][32 + lane] = sb2;
+        }
+        for (int e = tid; e < NBC * NBC; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            Ud[r][c] = (r < pw && c < pw && c >= r) ? U[(long)(p0 + r) * ld + p0 + c] : (r == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (wave < 2) {                            // wave 0: mu, wave 1: x
+            double* vec = wave == 0 ? h : xz;
+            double v = lane < pw ? vec[p0 + lane] - ((part[0][wave][lane] + part[1][wave][lane]) + (part[2][wave][lane] + part[3][wave][lane])) : 0.0;
+            for (int i = pw - 1; i >= 0; --i) {
+                const double xi = __shfl(v, i) / Ud[i][i];
+                if (lane == i) v = xi; else if (lane < i) v -= Ud[lane][i] * xi;
+            }
+            if (lane < pw) vec[p0 + lane] = v;
+        }
+        __syncthreads();
+    }
     // scatter: zeros for inactive blocks
     const int D = g.N * g.B;
     double* W = g.W + (long)n * D;
