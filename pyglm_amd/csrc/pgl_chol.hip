@@ -231,9 +231,6 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     if (na_max <= 0) return PGL_OK;
     hipLaunchKernelGGL(gather_active_kernel, dim3((na_max + 255) / 256, na_max, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
-    // 128-row super-panels: two 64-row sub-panels (diagonal factor + row-panel solve each, with a rank-64 update of the
-    // second sub-panel's 64-row strip in between), then ONE rank-128 update of the trailing matrix -- half the passes over
-    // the trailing matrix of a plain 64-row right-looking factorisation.
     auto trailing = [&](int krow0, int K, int c0, int mfix) -> int {
         // C[c0.., c0..] -= P' P with P = rows [krow0, krow0+K) of Ac, columns from c0 (k-major panel)
         PglGemmArgs t{};
@@ -244,7 +241,9 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
         t.C = s.Ac + (long)c0 * s.ldc + c0; t.ldc = s.ldc; t.strideC = s.strideC;
         t.N = rem; t.K = K; t.a_cols = rem + (rem & 1); t.b_cols = t.a_cols; t.nbatch = s.nb; t.nz_total = 0;
         t.alpha = -1.0; t.beta = 1.0; t.batch_k = nullptr; t.batch_dim = s.na; t.dim_off = c0; t.W = nullptr; t.ldw = 0;
-        if (mfix > 0) { t.M = mfix; t.tri = 0; t.dim_mode = 1; return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st); }   // strip: mfix rows only
+        // strip: mfix rows only -- and never rows past a neuron's own remainder (they would land in the padding or, beyond ldc, in the next
+        // neuron's block)
+        if (mfix > 0) { t.M = mfix; t.tri = 0; t.dim_mode = 3; return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st); }
         t.M = rem; t.tri = 2; t.dim_mode = 0;
         return pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     };
@@ -259,22 +258,27 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
         t.batch_dim = s.na; t.dim_off = c0; t.dim_mode = 1;
         return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st);
     };
-    for (int q0 = 0; q0 < na_max; q0 += 2 * NBC) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0);
-        PGL_CHECK_LAUNCH();
-        int rem = na_max - q0 - NBC;
-        if (rem <= 0) break;
-        int rc = panel_solve(q0);
-        if (rc) return rc;
-        rc = trailing(q0, NBC, q0 + NBC, NBC);              // strip: rows/cols of the second sub-panel
-        if (rc) return rc;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, q0 + NBC);
-        PGL_CHECK_LAUNCH();
-        rem = na_max - q0 - 2 * NBC;
-        if (rem <= 0) break;
-        rc = panel_solve(q0 + NBC);
-        if (rc) return rc;
-        rc = trailing(q0, 2 * NBC, q0 + 2 * NBC, 0);        // rank-128 update of everything right of / below the super-panel
+    // super-panels of SP 64-row sub-panels: before sub-panel i is factored its 64-row strip takes the updates of sub-panels 0..i-1 (one
+    // rank-64i strip update), and the trailing matrix is updated ONCE per super-panel with rank 64 SP.  The trailing passes stream the
+    // whole remaining matrix (HBM-bound at rank 128): SP = 4 halves them again.
+    constexpr int SP = 4;
+    bool done = false;
+    for (int q0 = 0; q0 < na_max && !done; q0 += SP * NBC) {
+        for (int i = 0; i < SP; ++i) {
+            const int qi = q0 + i * NBC;
+            if (qi >= na_max) { done = true; break; }
+            if (i > 0) {
+                const int rc = trailing(q0, i * NBC, qi, NBC);          // strip: rows of sub-panel i, columns from its diagonal block
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, qi);
+            PGL_CHECK_LAUNCH();
+            if (na_max - qi - NBC <= 0) { done = true; break; }
+            const int rc = panel_solve(qi);
+            if (rc) return rc;
+        }
+        if (done || na_max - q0 - SP * NBC <= 0) break;
+        const int rc = trailing(q0, SP * NBC, q0 + SP * NBC, 0);        // rank-256 update of everything right of / below the super-panel
         if (rc) return rc;
     }
     hipLaunchKernelGGL(solve_sample_kernel, dim3(s.nb), dim3(256), 0, st, g);

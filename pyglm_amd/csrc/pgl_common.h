@@ -45,7 +45,7 @@ struct PglGemmArgs {
     const int* batch_k;                        // optional per-batch K (multiple of 16; 0 = skip batch)
     int* sched;                                // persistent launch: 8 per-XCD work counters, zeroed before the launch
     const int* batch_dim; int dim_off;         // optional per-batch size d = max(0, batch_dim[b] - dim_off)
-    int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed
+    int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed;  3: M = min(g.M, d), N = d
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);

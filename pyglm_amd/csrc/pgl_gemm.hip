@@ -86,7 +86,8 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
         const int d = g.batch_dim[batch] - g.dim_off;
         if (g.dim_mode == 0) { Mv = d; Nv = d; }
         else if (g.dim_mode == 1) Nv = d;
-        else Mv = d;
+        else if (g.dim_mode == 2) Mv = d;
+        else { Mv = g.M < d ? g.M : d; Nv = d; }     // 3: a strip of at most g.M rows of a d x d remainder
     }
     if (tm * C::BM >= Mv || tn * C::BN >= Nv) return;
 

@@ -304,10 +304,13 @@ def test_sharded_equals_unsharded(torch_dev, gram):
         np.testing.assert_array_equal(joined, full[k])
 
 
-@pytest.mark.parametrize("N,B,T,rho", [(1, 3, 40, 0.5), (2, 1, 5, 0.5), (20, 10, 333, 0.5), (7, 32, 200, 0.6), (3, 2, 17, 0.0)])
+@pytest.mark.parametrize("N,B,T,rho", [(1, 3, 40, 0.5), (2, 1, 5, 0.5), (20, 10, 333, 0.5), (7, 32, 200, 0.6), (3, 2, 17, 0.0), (73, 1, 300, 1.0),
+                                      (50, 5, 400, 1.0)])
 def test_edge_shapes_vs_oracle(torch_dev, N, B, T, rho):
     """edges: a single neuron, T below one 16-row K tile / not a multiple of 16, the reference's default B = 10, the
-    largest supported B (= 32: 10 blocks per proposal window), rho = 0 everywhere (deterministic: all connections off)"""
+    largest supported B (= 32: 10 blocks per proposal window), rho = 0 everywhere (deterministic: all connections off), and two all-on
+    cases whose active dimension (74, 251) ends a few rows into a 64-row Cholesky sub-panel with the padded leading dimension (80, 256)
+    shorter than the sub-panel: a strip update must not write past a neuron's own rows"""
     from pyglm_amd.engine import make_draws
     rng = np.random.default_rng(100 + N + B)
     X = np.abs(rng.standard_normal((T, N, B))) * 0.4
