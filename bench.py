@@ -163,7 +163,11 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    barrier()
+    t_ll = time.perf_counter()
     ll = model.log_likelihood()
+    barrier()
+    t_ll = time.perf_counter() - t_ll          # log_likelihood() on its own: activation + fused reduction (+ scalar all-reduce)
     # the same sampler with the Gram forced onto the fp64-MFMA kernel, one more sweep of the same chain (not part of `value`)
     cmp64 = None
     took_i8 = any(ds.int8 for ds in model.engine.datasets)
@@ -219,7 +223,7 @@ def main():
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
                          "traffic": traffic, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
-            "setup_s": round(t_setup, 2), "log_likelihood_after": ll,
+            "setup_s": round(t_setup, 2), "log_likelihood_after": ll, "log_likelihood_ms": round(t_ll * 1e3, 2),
         }
         gi = stages.get("gram.int8")
         if gi and gi["ms"] > g["ms"]:
