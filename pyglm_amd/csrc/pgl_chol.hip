@@ -2,7 +2,7 @@
 //
 // Reference: pyglm/regression.py:323-340 (_resample_W): Jp = J_post[ix_(a,a)], hp = h_post[a],
 // [W_active; b] = sample_gaussian(J=Jp, h=hp)  ==  L = chol(Jp);  x = L^-T z + Jp^-1 hp   (pybasicbayes, published form).
-// Steps here: (1) compact the active sub-block (both triangles) into Ac; (2) blocked right-looking Cholesky in the
+// Steps here: (1) compact the active sub-block (upper triangle) into Ac; (2) blocked right-looking Cholesky in the
 // UPPER form Ac = U'U (U = L'), so every panel U[q0:q0+64, :] is k-major and feeds the fp64 MFMA contraction directly:
 // the 64 x 64 diagonal factor and its inverse are formed in LDS, the row-panel solve U12 = U11^-T A12 and the rank-64 /
 // rank-128 updates of the trailing matrix run on pgl_gemm.hip; (3) U'w = h, U mu = w, U x = z;  out = mu + x.
@@ -44,12 +44,12 @@ __global__ __launch_bounds__(256) void gather_active_kernel(CholArgs g) {
     const int na = g.na[n];
     const int i = blockIdx.y;                       // compact row
     const int j = blockIdx.x * 256 + threadIdx.x;   // compact col
-    if (i >= na || j >= na) return;
+    if (i >= na || j >= na || j < i) return;        // upper triangle only: nothing downstream reads below the diagonal of Ac
     const int* act = g.act + (long)n * g.ldact;
     const int gi = act[i], gj = act[j];
     const double* J = g.J + (long)n * g.strideJ;
     g.Ac[(long)n * g.strideC + (long)i * g.ldc + j] = gi >= gj ? J[(long)gi * g.ldj + gj] : J[(long)gj * g.ldj + gi];
-    if (j == 0) g.hc[(long)n * g.ldc + i] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
+    if (j == i) g.hc[(long)n * g.ldc + i] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
 }
 
 // factor the 64x64 diagonal block at q0: A11 = U11' U11, U11 written to the upper triangle in place
