@@ -190,3 +190,75 @@ def test_draws_made_ahead_equal_draws_made_on_time():
         out.append((m.adjacency.copy(), m.weights.copy(), m.biases.copy()))
     for x, y in zip(*out):
         np.testing.assert_array_equal(x, y)
+
+
+def test_integer_gram_arithmetic_on_the_host():
+    """the two pieces of exact arithmetic the integer-MFMA Gram rests on (pgl_i8gram.hip), replayed with NumPy / Python integers:
+    (a) a residue by four fp64 operations -- q = (v / p + M) - M with M = 1.5 * 2^52, r = v - p q: congruent to v and a signed byte for
+    every modulus and every |v| < 2^50;  (b) Garner's mixed-radix digits from unreduced partial sums reconstruct S exactly"""
+    P = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197]
+    from math import gcd
+    assert all(gcd(a, b) == 1 for i, a in enumerate(P) for b in P[i + 1:])
+    prod = 1
+    for p in P:
+        prod *= p
+    assert prod > 2 * 100000 * 2 ** 100 and prod > 2 * 112000 * 2 ** 100       # beta = 50 holds the integer Gram up to T = 112 000
+    rng = np.random.default_rng(3)
+    MAGIC = 6755399441055744.0
+    v = np.rint(rng.uniform(-1, 1, 200000) * 2.0 ** 50)
+    v[:6] = [0.0, 2.0 ** 50 - 1, -(2.0 ** 50 - 1), 127.5 * 255 // 1, 128.0 * 255, -128.0 * 255]
+    vi = v.astype(np.int64)
+    for p in P[1:]:
+        q = (v * (1.0 / p) + MAGIC) - MAGIC                      # rint(v / p) up to an error of 2^-9.6
+        assert np.all(q == np.rint(q))
+        r = vi - p * q.astype(np.int64)                          # the fma is exact: the true result is a small integer
+        assert np.all((r - vi) % p == 0) and r.min() >= -128 and r.max() <= 127
+    low = (vi & 0xff).astype(np.uint8).view(np.int8).astype(np.int64)          # p = 256: the low byte of the integer
+    assert np.all((low - vi) % 256 == 0)
+    # (b) tables as in ModTable, digits with symmetric representatives, Horner
+    NP_ = len(P)
+    w = [[0] * NP_ for _ in range(NP_)]
+    pinv = [0] * NP_
+    for qd in range(1, NP_):
+        pr = 1
+        for k in range(qd):
+            w[k][qd] = pr - P[qd] if pr > P[qd] // 2 else pr
+            pr = (pr * (P[k] % P[qd])) % P[qd]
+        pinv[qd] = pow(pr, -1, P[qd])
+
+    def trunc_mod(a, p):                                          # C++ % (truncating)
+        return -(-a % p) if a < 0 else a % p
+    import random
+    random.seed(5)
+    for _ in range(3000):
+        S = random.randrange(-prod // 2 + 2 ** 20, prod // 2 - 2 ** 20)
+        d = []
+        for p in P:
+            r = S % p
+            if p == 256:
+                r = r - 256 if r >= 128 else r
+            else:
+                r = r - p if r > p // 2 else r
+                if random.random() < 0.1 and -128 <= r + p <= 127:
+                    r += p                                        # a non-minimal representative, as the planes kernel may produce
+                if random.random() < 0.1 and -128 <= r - p <= 127:
+                    r -= p
+            d.append(r)
+        # the GEMM re-reduces to the symmetric representative before the CRT
+        d = [d[0]] + [((x + p // 2) % p) - p // 2 for x, p in zip(d[1:], P[1:])]
+        for qd in range(1, NP_):
+            p = P[qd]
+            u = d[qd]
+            for k in range(qd):
+                u -= d[k] * w[k][qd]
+            assert abs(u) < 2 ** 18
+            t = trunc_mod(u * pinv[qd], p)
+            if t > p // 2:
+                t -= p
+            elif t < -(p // 2):
+                t += p
+            d[qd] = t
+        s = 0
+        for qd in range(NP_ - 1, -1, -1):
+            s = s * P[qd] + d[qd]
+        assert s == S
