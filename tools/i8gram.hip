@@ -272,7 +272,7 @@ __device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const 
     // two tiles per iteration so that the B buffers alternate with compile-time indices
     // VAR & 64: on a diagonal tile the 16 x 16 blocks that lie entirely above the diagonal are not multiplied (47 % of such a tile)
     unsigned skip1 = 0, skip2 = 0;
-    if ((VAR & 64) && tm == tn)
+    if ((VAR & (64 | 256)) && tm == tn)
         for (int m = 0; m < 16; ++m) {
             if (wm * 8 + (m >> 2) < wn * 4 + (m & 3)) skip1 |= 1u << m;
             if (wm * 8 + 4 + (m >> 2) < wn * 4 + (m & 3)) skip2 |= 1u << m;
@@ -311,7 +311,10 @@ __device__ __forceinline__ void i8gram_item16(const Args& g, const int q, const 
         cur = nxt;
     };
     int kt = 0;
-    if ((VAR & 64) && tm == tn) {
+    if constexpr ((VAR & 256) != 0) {          // a launch of diagonal tiles only: one code path, the skipping one
+        for (; kt + 1 < nkt; kt += 2) { tile(std::integral_constant<int, 0>{}, std::true_type{}, kt); tile(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1); }
+        if (kt < nkt) tile(std::integral_constant<int, 0>{}, std::true_type{}, kt);
+    } else if ((VAR & 64) && tm == tn) {
         for (; kt + 1 < nkt; kt += 2) { tile(std::integral_constant<int, 0>{}, std::true_type{}, kt); tile(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1); }
         if (kt < nkt) tile(std::integral_constant<int, 0>{}, std::true_type{}, kt);
     } else {
@@ -420,7 +423,10 @@ static void run(int D, int K, int Q, bool check, int sustain = 0) {
         for (int q = 0; q < Q; ++q)
             for (int r0 = 0; r0 < ntm; r0 += RG, ++r)
                 for (int tn = 0; tn < std::min(ntm, r0 + RG); ++tn)
-                    for (int tm = std::max(tn, r0); tm < std::min(ntm, r0 + RG); ++tm) L[r % 8].push_back(q << 16 | tm << 8 | tn);
+                    for (int tm = std::max(tn, r0); tm < std::min(ntm, r0 + RG); ++tm) {
+                        if (((VAR & 256) != 0) != (tm == tn) && (VAR & 512)) continue;      // VAR & 512: split launches (256: the diagonal part)
+                        L[((VAR & 256) ? (r * RG + tm) : r) % 8].push_back(q << 16 | tm << 8 | tn);
+                    }
     }
     int maxlen = 0, hl[8];
     for (int y = 0; y < 8; ++y) { hl[y] = (int)L[y].size(); maxlen = std::max(maxlen, hl[y]); }
@@ -472,16 +478,18 @@ static void run(int D, int K, int Q, bool check, int sustain = 0) {
 int main(int argc, char** argv) {
     // VAR bits: 1 scalar-base requests, 2 requests spread over both k-steps, 4 blocked plane layout, 8 snake MFMA order, 16 dead wave tiles of
     // diagonal tiles skipped, 32 v_mfma_i32_16x16x64_i8 pipeline (what the library runs), 64 16x16 blocks above the diagonal skipped,
-    // 128 host-built per-XCD item lists (row groups of RG tile rows);  ABL bits: see i8gram_item.   argv[1] = n: n x 20 sustained launches
+    // 128 host-built per-XCD item lists (row groups of RG tile rows), 512 split launches: off-diagonal items (and with 256 the diagonal
+    // items, one skipping code path);  ABL bits: see i8gram_item.   argv[1] = n: n x 20 sustained launches
     if (argc > 1) {
         const int n = atoi(argv[1]);
-        run<0, true, 38>(5120, 100096, 60, false, n);
+        run<0, true, 166>(5120, 100096, 60, false, n);             // all items, one launch
+        run<0, true, 166 + 512>(5120, 100096, 60, false, n);       // off-diagonal items only
+        run<0, true, 166 + 512 + 256>(5120, 100096, 60, false, n); // diagonal items only, blocks above the diagonal skipped
         return 0;
     }
-    run<0, true, 6>(3584, 320, 2, true);
     run<0, true, 38>(3584, 320, 2, true);
-    run<0, true, 38>(1024, 384, 3, true);
     run<0, true, 166>(3584, 320, 2, true);
-    run<0, true, 38>(5120, 100096, 60, false);
+    run<0, true, 166 + 512>(1024, 384, 3, false);
+    run<0, true, 166 + 512 + 256>(1024, 384, 3, false);
     return 0;
 }
