@@ -1,9 +1,17 @@
 #!/usr/bin/env python
-"""Headline benchmark: full Gibbs sweeps/sec (SparseBernoulliGLM.resample_model) at N=1024, T=100k, B=5 on synthetic
-spike trains, neurons sharded over --gpus MI355X (one process per GPU; launch with torch.distributed.run for N>1).
+"""Headline benchmark: full Gibbs sweeps/sec (SparseBernoulliGLM.resample_model) at N=1024, T=100k, B=5 on synthetic spike trains,
+neurons sharded over --gpus MI355X, one process per GPU over RCCL.
 
-One JSON line on rank 0 (contract in the task statement): value = sweeps/s of the WHOLE model, `roofline` for the dominant
-kernel (omega-weighted fp64 Gram, MFMA-bound), `cpu_baseline` = the oracle timed on this box's host cores on a bounded sample.
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no launcher around it (WORLD_SIZE unset) the script starts its N ranks itself, as fresh processes, before anything has
+touched a GPU; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is one of the ranks.
+
+One JSON line on rank 0 (contract in the task statement): `value` = sweeps/s of the WHOLE model (max over ranks of the timed region),
+`roofline` for the dominant kernel (the integer-MFMA Gram) from HIP events recorded on the launch stream, `hbm_stage` for the streaming
+kernel next to it (residue-plane conversion), `per_rank` timings incl. the time inside collectives and the host-only share,
+`int8_vs_fp64` = one sweep from the same state on both Gram paths, `fp64_gram_path` = the same sampler with the Gram on the fp64 kernel,
+`cpu_baseline` = the oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -24,8 +32,9 @@ CONFIGS = {   # BASELINE.json configs
     "cfg3g": dict(N=1024, B=5, T=100000, L=100, obs="gaussian"),  # not in BASELINE.json: SparseGaussianGLM at the cfg3 shape
 }
 PEAK_HBM_GBS = 8000.0
-PEAK_I8_MFMA_TOPS = 5000.0
+PEAK_I8_MFMA_TOPS = 5000.0    # dense i8 MFMA, 2x the bf16 figure of MI355X_MICROARCH.md (4.92 POP/s measured at 2.39 GHz on constant operands)
 PEAK_F64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 64 cyc (tools/ubench2_f64.hip, measured)
+TOP_STAGES = ("activation", "pg_loglik", "border", "gram", "gram.stats", "gram.planes", "gram.int8", "gram.crt", "gram_scale", "flips", "weights")
 
 
 def synth(N, B, T, L, seed=0):
@@ -37,44 +46,86 @@ def synth(N, B, T, L, seed=0):
     return basis, Y
 
 
-def cpu_baseline(model, cfg, budget_s=20.0):
-    """The oracle (NumPy/BLAS restatement of the reference, oracle/pyglm_oracle.py) on this host's cores, for ONE neuron of the
-    same workload, on a bounded sample: T_s time bins of the Gram/activation (cost linear in T) and P of the N flip proposals
-    (each proposal costs the same), extrapolated to one full sweep of N neurons.  Labelled as extrapolated."""
+def cpu_baseline(model, cfg, neurons=2, proposals=32, budget_s=150.0):
+    """The oracle (NumPy/BLAS restatement of the reference, oracle/pyglm_oracle.py + the C PG sampler) on this host's cores for `neurons`
+    WHOLE neuron regressions of the same workload: activation, PG draw, the full-T likelihood statistics (the T x D
+    temporary and the full dgemm of regression.py:251-252) and the weight draw are run in full; of the N collapsed-flip proposals (each costs
+    the same two dense Choleskys, regression.py:343-378) the first `proposals` are run and scaled to N.  The sweep is N identical-cost
+    neurons (models.py:169-171), so the per-neuron time is scaled by N / neurons.  Labelled as extrapolated."""
     from oracle import pyglm_oracle as orc
     N, B, T = cfg["N"], cfg["B"], cfg["T"]
     D = N * B
     eng = model.engine
-    Ts = int(min(T, max(2000, 4e10 / (2.0 * D * D))))         # ~4e10 flop of dgemm
-    P = min(N, 8)
-    X = eng.datasets[0].X[:Ts, :D].cpu().numpy()
-    om = eng.datasets[0].OK[:Ts, 0].cpu().numpy()
-    y = model.data_list[0][1][:Ts, model.n0].astype(float)
-    r0 = model.regressions[model.n0]
-    r = orc.Regression(N, B, rho=r0.rho.copy(), mu_w=r0.mu_w.copy(), S_w=r0.S_w.copy(), mu_b=r0.mu_b.copy(), S_b=r0.S_b.copy())
-    r.a, r.W, r.b = r0.a.copy(), r0.W.copy(), r0.b.copy()
+    ds = eng.datasets[0]
+    X = ds.X[:T, :D].cpu().numpy()
     rng = np.random.default_rng(1)
-    t0 = time.perf_counter()
-    psi = r.activation(X)
-    _ = orc.pg_draw(None, psi, 1, 0)
-    t_act = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    Jp, hp = r.prior_stats()
-    Jl, hl = r.lkhd_stats([(X, y)], [om])
-    t_gram = time.perf_counter() - t0
-    Jq, hq = Jp + Jl * (T / Ts), hp + hl * (T / Ts)
-    t0 = time.perf_counter()
-    r.collapsed_resample_a(Jp, hp, Jq, hq, rng.permutation(N)[:P], rng.random(P))
-    t_flip = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    r.resample_W(Jq, hq, rng.standard_normal(D + 1))
-    t_w = time.perf_counter() - t0
-    t_neuron = (t_act + t_gram) * (T / Ts) + t_flip * (N / P) + t_w
+    t_wall = time.perf_counter()
+    per = []
+    for i in range(neurons):
+        n = model.n0 + i
+        r0 = model.regressions[n]
+        rho, S_w, mu_w, S_b, mu_b = r0._hyper()
+        r = orc.Regression(N, B, rho=rho.copy(), mu_w=mu_w.copy(), S_w=S_w.copy(), mu_b=mu_b.copy(), S_b=S_b.copy())
+        r.a, r.W, r.b = r0.a.copy(), r0.W.copy(), r0.b.copy()
+        y = model.data_list[0][1][:, n].astype(float)
+        t0 = time.perf_counter()
+        psi = r.activation(X)
+        om = orc.pg_draw(None, psi, 1, n)
+        t_act = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Jp, hp = r.prior_stats()
+        Jl, hl = r.lkhd_stats([(X, y)], [om])
+        t_gram = time.perf_counter() - t0
+        Jq, hq = Jp + Jl, hp + hl
+        P = min(N, proposals)
+        if time.perf_counter() - t_wall > budget_s:
+            P = min(P, 8)
+        t0 = time.perf_counter()
+        r.collapsed_resample_a(Jp, hp, Jq, hq, rng.permutation(N)[:P], rng.random(P))
+        t_flip = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        r.resample_W(Jq, hq, rng.standard_normal(D + 1))
+        t_w = time.perf_counter() - t0
+        per.append((t_act, t_gram, t_flip * (N / P), t_w, P))
+        del Jp, Jl, Jq
+    t_neuron = float(np.mean([p[0] + p[1] + p[2] + p[3] for p in per]))
+    m = np.mean(np.array([p[:4] for p in per]), axis=0)
     return dict(value=1.0 / (N * t_neuron), unit="sweeps/s", cores=os.cpu_count(), kind="port",
-                sample="oracle (NumPy/OpenBLAS all cores + OpenMP PG), 1 of %d neurons, T_s=%d of %d bins for activation/PG/Gram "
-                       "(x%.0f), %d of %d flip proposals (x%.0f), full weight draw; extrapolated to N neurons; "
-                       "per-neuron s: act+pg %.3f gram %.3f flips %.3f weights %.3f" %
-                       (N, Ts, T, T / Ts, P, N, N / P, t_act * T / Ts, t_gram * T / Ts, t_flip * N / P, t_w))
+                sample="oracle (NumPy/OpenBLAS on all cores + OpenMP PG sampler), %d whole neuron regressions of %d at full T = %d (activation, "
+                       "PG draws, full likelihood statistics, weight draw), %s of %d flip proposals each (scaled x%.0f); extrapolated x%d to N "
+                       "neurons; mean per-neuron seconds: act+pg %.2f, gram %.2f, flips %.1f (scaled), weights %.2f; measured in %.0f s"
+                       % (neurons, N, T, "/".join(str(p[4]) for p in per), N, N / per[0][4], N // neurons, m[0], m[1], m[2], m[3],
+                          time.perf_counter() - t_wall))
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torchrun: N child processes of this same script, one per GPU, rendezvous on 127.0.0.1 at a free
+    port.  Children inherit stdout/stderr (only rank 0 prints the JSON line).  Any rank failing ends the others; exit code = first failure."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -91,20 +142,27 @@ def main():
     ap.add_argument("--gram", default="auto", choices=["auto", "fp64", "int8"],
                     help="likelihood Gram: auto (the engine's default: exact integer arithmetic on the int8 MFMA where that is faster, DESIGN.md "
                          "section 8c), or forced onto the fp64 MFMA kernel / the int8 path")
+    ap.add_argument("--planes", type=int, default=None, help="residue planes (moduli) of the integer Gram (default: the engine's, 13)")
     ap.add_argument("--no-fp64-compare", action="store_true",
-                    help="skip the extra (untimed for `value`) sweep with the fp64-MFMA Gram that fills the fp64_gram_path object")
+                    help="skip the extra sweeps (untimed for `value`) that fill int8_vs_fp64 and fp64_gram_path")
+    ap.add_argument("--fp64-steps", type=int, default=3, help="sweeps timed with the Gram on the fp64-MFMA kernel for fp64_gram_path")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("N", "T", "B"):
         if getattr(args, k):
             cfg[k] = getattr(args, k)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start one fresh process per GPU ourselves.  This parent has not touched the GPU (torch is not even
+        # imported yet) and never will: it only waits for the ranks and passes rank 0's JSON line through.
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     # test hooks for boxes with a single GPU: PGL_BENCH_DEVICE puts every rank on one device, PGL_DIST_BACKEND=gloo replaces RCCL
     # (which refuses two ranks on one device) -- the launch path, sharding, gathers and the max-over-ranks timing are then the real ones
     if os.environ.get("PGL_BENCH_DEVICE"):
@@ -119,15 +177,32 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"
+
+    def allmax(x):
+        if not use_dist:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM, SparseGaussianGLM
     N, B, T, L = cfg["N"], cfg["B"], cfg["T"], cfg["L"]
     np.random.seed(0)
     basis, Y = synth(N, B, T, L)
     t_setup = time.perf_counter()
-    ekw = dict(batch=args.batch) if args.batch else {}
+    ekw = {}
+    if args.batch:
+        ekw["batch"] = args.batch
     if args.gram != "auto":
         ekw["gram"] = args.gram
+    if args.planes:
+        ekw["planes"] = args.planes
     ekw = ekw or None
     if cfg.get("obs") == "negbin":
         Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)     # counts, mean 0.35
@@ -141,114 +216,147 @@ def main():
     model.add_data(Y)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
+    eng = model.engine
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def timed(steps):
+        """`steps` sweeps bracketed by barrier + synchronize on both sides -> (max-over-ranks seconds, this rank's seconds, stage table,
+        seconds this rank spent inside collectives)"""
+        eng.profile = True
+        eng.collect_timings()
+        c0 = model.comm_seconds
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.resample_model()
+        barrier()
+        mine = time.perf_counter() - t0
+        st = eng.collect_timings()
+        eng.profile = False
+        return allmax(mine), mine, st, model.comm_seconds - c0
 
     for _ in range(args.warmup):
         model.resample_model()
-    model.engine.profile = True
-    model.engine.collect_timings()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.resample_model()
-    barrier()
-    dt = time.perf_counter() - t0
-    stages = model.engine.collect_timings()
-    model.engine.profile = False
+    dt, dt_mine, stages, comm_s = timed(args.steps)
+
+    # per-rank breakdown: wall time, time inside collectives, GPU time of the top-level stages, and what is left (host-only share)
+    gpu_ms = sum(v["ms"] for k, v in stages.items() if k in TOP_STAGES)
+    mine = {"rank": rank, "neurons": model.n1 - model.n0, "ms_per_step": dt_mine / args.steps * 1e3,
+            "collectives_ms_per_step": comm_s / args.steps * 1e3, "gpu_stage_ms_per_step": gpu_ms / args.steps,
+            "host_only_ms_per_step": max(0.0, dt_mine * 1e3 - gpu_ms) / args.steps}
+    per_rank = [mine]
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     barrier()
     t_ll = time.perf_counter()
     ll = model.log_likelihood()
     barrier()
     t_ll = time.perf_counter() - t_ll          # log_likelihood() on its own (SURVEY 8(d)): activation + fused reduction (+ scalar all-reduce)
-    # the same sampler with the Gram forced onto the fp64-MFMA kernel, one more sweep of the same chain (not part of `value`)
-    cmp64 = None
-    took_i8 = any(ds.int8 for ds in model.engine.datasets)
-    if use_dist:      # the extra sweep contains collectives: every rank runs it, or none (a rank short of memory may have stayed on fp64)
-        t = torch.tensor([float(took_i8)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        took_i8 = bool(t.item())
+
+    # ---- the two Gram paths from the same state (consistency), then the fp64 path timed on its own
+    cmp64 = consistency = None
+    took_i8 = bool(allmax(float(any(ds.int8 for ds in eng.datasets))))      # every rank runs the extra sweeps, or none
     if took_i8 and not args.no_fp64_compare:
-        for ds in model.engine.datasets:
-            ds.int8 = False
-        model.engine.profile = True
-        model.engine.collect_timings()
-        barrier()
-        t1 = time.perf_counter()
+        state = model.get_state()
         model.resample_model()
-        barrier()
-        dt64 = time.perf_counter() - t1
-        st64 = model.engine.collect_timings()
-        model.engine.profile = False
-        if use_dist:
-            t = torch.tensor([dt64], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt64 = float(t.item())
-        g64 = st64.get("gram", dict(ms=0.0, calls=0, work=0.0))
+        ll_i8 = model.log_likelihood()
+        A_i8, W_i8 = model.adjacency, model.weights
+        model.set_state(state)
+        for ds in eng.datasets:
+            ds.int8 = False
+        d1, _, st64, _ = timed(1)
+        ll_f64 = model.log_likelihood()
+        A_f64, W_f64 = model.adjacency, model.weights
+        consistency = {"note": "one sweep from the same chain state with the Gram on the integer matrix cores and on the fp64 kernel",
+                       "log_likelihood_int8": ll_i8, "log_likelihood_fp64": ll_f64, "rel_diff": abs(ll_i8 - ll_f64) / abs(ll_f64),
+                       "adjacency_equal": bool(np.array_equal(A_i8, A_f64)), "flips_differing": int((A_i8 != A_f64).sum()),
+                       "max_abs_weight_diff": float(np.abs(W_i8 - W_f64).max())}
+        del A_i8, W_i8, A_f64, W_f64, state
+        more = max(0, args.fp64_steps - 1)
+        d2, st2 = 0.0, {}
+        if more:
+            d2, _, st2, _ = timed(more)
+        nst = 1 + more
+        dt64 = d1 + d2
+        g64 = {k: st64.get("gram", {}).get(k, 0.0) + st2.get("gram", {}).get(k, 0.0) for k in ("ms", "calls", "work")}
         a64 = (g64["work"] / (g64["ms"] * 1e-3) * 1e-12) if g64["ms"] > 0 else None
-        cmp64 = {"value": 1.0 / dt64, "unit": "sweeps/s", "ms_per_step": dt64 * 1e3, "steps": 1,
-                 "note": "one further sweep of the same chain with the Gram on the fp64-MFMA kernel (engine gram='fp64')",
+        cmp64 = {"value": nst / dt64, "unit": "sweeps/s", "ms_per_step": dt64 / nst * 1e3, "steps": nst,
+                 "note": "further sweeps of the same chain with the Gram on the fp64-MFMA kernel (engine gram='fp64')",
                  "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": a64,
                               "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (a64 / PEAK_F64_MFMA_TFLOPS) if a64 else None,
                               "launches": g64["calls"], "avg_launch_ms": (g64["ms"] / g64["calls"]) if g64["calls"] else None}}
+        for ds in eng.datasets:
+            ds.int8 = True
 
     if rank == 0:
-        g = stages.get("gram", dict(ms=0.0, calls=0, work=0.0))
+        def stage(name):
+            return stages.get(name, dict(ms=0.0, calls=0, work=0.0))
+        g = stage("gram")
         achieved = (g["work"] / (g["ms"] * 1e-3) * 1e-12) if g["ms"] > 0 else None
-        # HBM bytes per Gram launch from the committed rocprofv3 --pmc passes (profiles/gram_pmc.json); only valid for the
-        # workload and launch geometry they were collected on (cfg3, one GPU)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "gram_pmc.json")
-        pmc_ok = os.path.exists(pmc) and args.config == "cfg3" and world == 1 and (N, B, T) == (1024, 5, 100000)
-        if pmc_ok:
+        # HBM-side bytes per Gram launch come from separate rocprofv3 --pmc passes of this same command (profiles/gram_pmc.json, committed);
+        # they are NOT measured in this run, and only quoted for the workload and launch geometry they were collected on
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "gram_pmc.json")
+        if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
             except Exception:
-                traffic = None
+                pmc = {}
+        pmc_ok = args.config == "cfg3" and world == 1 and (N, B, T) == (1024, 5, 100000)
         out = {
             "metric": "Gibbs sweeps/sec (full resample_model)", "value": args.steps / dt, "unit": "sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s N=%d B=%d L=%d T=%d, synthetic i.i.d. %s, neurons sharded over %d GPU(s)"
                                    % (type(model).__name__, N, B, L, T, {"negbin": "NB(2, 0.85) counts", "gaussian": "N(2 s, 1) activity"}.get(cfg.get("obs"), "Bernoulli(0.08) spikes"), world), "N": N, "B": B, "T": T, "parallelism": "neuron-shard x%d" % world,
-                       "neurons_per_batch": model.engine.nb},
+                       "neurons_per_batch": eng.nb},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
-                         "traffic": traffic, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
+                         "traffic": None, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
+            "per_rank": per_rank,
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll, "log_likelihood_ms": round(t_ll * 1e3, 2),
         }
-        gi = stages.get("gram.int8")
-        if gi and gi["ms"] > g["ms"]:
-            # the Gram went through the integer matrix cores: 15 int8 residue-plane products per neuron, T D (D+1) operations each (lower
-            # triangle, 2 per multiply-add); HIP events around i8_gram_kernel alone (conversion = stage gram.planes, CRT = gram.crt).
-            # peak: dense i8 MFMA 5 POP/s (2x the bf16 figure of MI355X_MICROARCH.md; 4.92 measured at 2.39 GHz with constant operands;
-            # with random operand bytes the package power limit holds the bare MFMA loop to 3.45 POP/s at 1.77 GHz: tools/ubench_i8.hip)
-            ach = 15.0 * gi["work"] / (gi["ms"] * 1e-3) * 1e-12
-            tr = None
-            if pmc_ok:
-                try:
-                    tr = json.load(open(pmc)).get("int8", {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    tr = None
-            out["dtype"] = "f64 (likelihood Gram: exact integer arithmetic on i8 residue planes, CRT back to f64)"
-            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_16x16x64_i8; 15 residue planes of %d neurons per launch)" % (model.engine._i8_scratch[2] if model.engine._i8_scratch else 0),
-                               "achieved": ach, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS, "traffic": tr,
-                               "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"],
+        gi = stage("gram.int8")
+        if gi["ms"] > g["ms"]:
+            # the Gram went through the integer matrix cores: `planes` int8 residue-plane products per neuron, T D (D+1) operations each
+            # (lower triangle, 2 per multiply-add); HIP events around i8_gram_kernel alone on the launch stream (column statistics =
+            # gram.stats, conversion = gram.planes, CRT = gram.crt).  With random operand bytes the package power limit holds the bare
+            # MFMA loop to 4.0 POP/s (tools/ubench_i8.hip, profiles/r01_power_limit.md)
+            npl = eng.planes
+            grp = eng._i8_scratch[2] if eng._i8_scratch else 0
+            ach = npl * gi["work"] / (gi["ms"] * 1e-3) * 1e-12
+            i8p = pmc.get("int8", {})
+            tr_ok = pmc_ok and i8p.get("planes") == npl and i8p.get("group") == grp
+            out["dtype"] = "f64 (likelihood Gram: exact integer arithmetic on %d i8 residue planes, CRT back to f64)" % npl
+            out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_16x16x64_i8; %d residue planes of %d neurons per launch)" % (npl, grp),
+                               "achieved": ach, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS,
+                               "traffic": i8p.get("hbm_bytes_per_launch") if tr_ok else None,
+                               "traffic_source": "profiles/gram_pmc.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)" if tr_ok else None,
+                               "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"], "planes": npl,
+                               "algorithmic_ops_per_launch": npl * gi["work"] / gi["calls"],
                                "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,
                                "power_limited_mfma_only_tops": 4000.0}
+            gp = stage("gram.planes")
+            if gp["ms"] > 0:
+                # i8_planes_kernel: reads X once per group (8 B per element) and stores `planes` bytes per element and neuron
+                byts = gp["work"] + 8.0 * T * (N * B) * gp["calls"]
+                gbs = byts / (gp["ms"] * 1e-3) * 1e-9
+                out["hbm_stage"] = {"bound": "hbm", "kernel": "i8_planes_kernel (fp64 -> %d residue planes, %d neurons per pass over X)" % (npl, grp),
+                                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                    "launches": gp["calls"], "avg_launch_ms": gp["ms"] / gp["calls"], "bytes_per_launch": byts / gp["calls"]}
+            if consistency:
+                out["int8_vs_fp64"] = consistency
             if cmp64:
                 out["fp64_gram_path"] = cmp64
+        pl = stage("pg_loglik")
+        if pl["ms"] > 0:
+            out["stage_E_note"] = ("pg_loglik_kernel: %.1f M PG draws/s; bound by the sampler's transcendental VALU work (rejection loops), not by "
+                                   "HBM (40 B per draw = %.2f TB/s)" % (pl["work"] / (pl["ms"] * 1e-3) * 1e-6, 40.0 * pl["work"] / (pl["ms"] * 1e-3) * 1e-12))
         if cfg.get("obs") == "gaussian":
             # no per-neuron Gram here: X'X is formed once in add_data and only scaled per sweep (HBM-bound streaming store)
-            gs = stages.get("gram_scale", dict(ms=0.0, calls=0, work=0.0))
+            gs = stage("gram_scale")
             ach = gs["work"] / (gs["ms"] * 1e-3) * 1e-9 if gs["ms"] > 0 else None
             out["roofline"] = {"bound": "hbm", "kernel": "scaled_gram_kernel (J[n] = X'X / eta_n, lower triangle)", "achieved": ach,
                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS if ach else None, "traffic": None,

@@ -4,8 +4,11 @@
  * The reference is pure Python; its native boundary on this path is (a) the third-party `pypolyagamma`
  * sampler and (b) BLAS/LAPACK reached through NumPy/SciPy.  Each entry point below names the reference
  * call site(s) it replaces (paths relative to /root/reference).  Conventions:
- *   - every pointer is a DEVICE pointer unless marked host; the caller owns every buffer, the library borrows it
- *     for the call only and allocates nothing persistent;
+ *   - every pointer is a DEVICE pointer unless marked host; the caller owns every data buffer, the library borrows it
+ *     for the call only.  The one thing the library allocates itself: per device, on first use, an 8 KiB ring of work
+ *     counters for its persistent launches (pgl_gemm.hip, sched_slot), kept until the process ends;
+ *   - calls act on the CURRENT HIP device (hipSetDevice by the caller); library state (kernel attributes, CU count, the
+ *     counter ring) is kept per device, so one process may drive several GPUs;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it;
  *   - return value 0 = ok, non-zero = error, message from pgl_last_error() (host, thread-local);
  *   - no hidden RNG state: stochastic entries take (seed, stream-id, element) counters (see oracle/pg_oracle.c
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 1
+#define PGL_ABI_VERSION 2
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -86,25 +89,37 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
                            const double* hw, const int* label, const double* Jb, const double* hb, int nb, int N, int B, void* hip_stream);
 
 /* ---- the same weighted Gram on the INTEGER matrix cores -------------------------------------------
- * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to beta-bit fixed point
- * (A = rint(x 2^e), B = rint(omega x 2^f); beta = 50 for T <= 112 000 time bins, the largest value with T 2^(2 beta) < prod(p)/2 beyond):
- * one int8 GEMM per modulus for 15 pairwise coprime moduli <= 256, int32 accumulation (re-reduced every 128 000 bins), exact
- * Chinese-remainder reconstruction, J = S 2^-(e+f).  Error ~1e-15 |a_i||b_j|, the level of the fp64 product itself.
- *   pgl_i8_colmax   out[c] = max(out[c], max_t |V[t][c]|)   (out zero-filled by the caller; X columns once, omega columns per sweep)
- *   pgl_i8_planes   residue planes [G][15] of Dq * Kp signed bytes each (Dq = D rounded up to 256, Kp = T rounded up to 64, at least 256),
- *                   BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024 +
- *                   (r % 16) 64; of X (Om = NULL, G = 1) or of omega_g X for the G columns of Om; sizes from pgl_i8_plane_bytes
- *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower 256 x 256 tiles, [G][15][Dq][Dq] signed bytes
- *                   (G * pgl_i8_residue_bytes(D))
- *   pgl_i8_crt      J[g] (+)= X' diag(omega_g) X, lower triangle, from the residues */
+ * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to integers
+ *     A[t][i] = rint(x_ti sA_i),   B_g[t][j] = rint((omega_gt x_tj) sB_gj),      sA, sB powers of two,
+ * one int8 GEMM per modulus for the first `nplanes` of 15 pairwise coprime moduli <= 256 (256, 255, 253, 251, 247, 241, 239, 233, 229,
+ * 227, 223, 217, 211, 199, 197), int32 accumulation (re-reduced every 128 000 bins), exact Chinese-remainder reconstruction,
+ * J_ij = S_ij / (sA_i sB_gj).  The scales are set from each column's Euclidean norm and largest element so that the integer columns have
+ * norms in [2^(nu-1), 2^nu) (nu = pgl_i8_norm_bits(nplanes, T): 50 / 54 / 58 for 13 / 14 / 15 moduli) unless their largest element would
+ * reach 2^50; Cauchy-Schwarz then keeps every |S_ij| inside the CRT range for any data, and the rounding error of J_ij has standard
+ * deviation sqrt((|A_i|^-2 + |B_gj|^-2) / 12) |a_i||b_gj| (<= 7.3e-16 |a_i||b_gj| at 13 moduli): pinned to the column norms.
+ *   pgl_i8_colstats amax[g][c] = max_t |v_tc|, sumsq[g][c] = sum_t v_tc^2 with v = X (Om = NULL, G = 1) or Om[:, g] * X, G <= 8; one pass
+ *                   over X, deterministic (fixed summation order)
+ *   pgl_i8_scales   scale[k] from (amax[k], sumsq[k]) for ncols = G * D columns (1 for an empty column, NaN for a non-finite one)
+ *   pgl_i8_planes   residue planes [G][nplanes] of Dq * Kp signed bytes each (Dq = D rounded up to 256, Kp = T rounded up to 64, at least
+ *                   256), BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024
+ *                   + (r % 16) 64; of X (Om = NULL, G = 1) or of omega_g X for the G columns of Om; scale [G][D]; buffer sizes from
+ *                   pgl_i8_plane_bytes (per neuron, at the full 15 planes)
+ *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower 256 x 256 tiles, [G][nplanes][Dq][Dq] signed bytes
+ *                   (buffer: G * pgl_i8_residue_bytes(D))
+ *   pgl_i8_crt      J[g] (+)= X' diag(omega_g) X, lower triangle, from the residues (scale_x [D], scale_wx [G][D])
+ * The same nplanes must be used for the scales, both plane sets, the product and the reconstruction. */
+int pgl_i8_max_planes(void);                     /* 15 */
+int pgl_i8_min_planes(int T);                    /* fewest moduli with norm bits >= 50 (error at the fp64 product's level): 13 */
+int pgl_i8_norm_bits(int nplanes, int T);        /* nu(nplanes, T) */
 size_t pgl_i8_plane_bytes(int D, int T);
 size_t pgl_i8_residue_bytes(int D);
-int pgl_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, void* hip_stream);
-int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* xmax, const double* wmax, void* planes, int T, int D, int G,
+int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* hip_stream);
+int pgl_i8_scales(const double* amax, const double* sumsq, long ncols, int T, int nplanes, double* scale, void* hip_stream);
+int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
                   void* hip_stream);
-int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, void* hip_stream);
-int pgl_i8_crt(const void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ, int T, int D, int G, int accumulate,
-               void* hip_stream);
+int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, int nplanes, void* hip_stream);
+int pgl_i8_crt(const void* residues, const double* scale_x, const double* scale_wx, double* J, long ldj, long strideJ, int T, int D, int G,
+               int nplanes, int accumulate, void* hip_stream);
 
 /* ---- collapsed adjacency resampling (pyglm/regression.py:282-320 + 343-378) ------------------------------------ */
 typedef struct {
@@ -125,6 +140,9 @@ typedef struct {
     int visit_order;                     /* 0: tableau rows in J's order.  1: rows / columns in PROPOSAL order (position k = block perm[k];
                                           * bias and potential rows last; built by pgl_flip_visit_order): d_idx are positions, and the
                                           * update after window w touches only the rows not yet proposed */
+    double* logodds;                     /* [nb][N] or NULL.  out: logodds[n][k] = lps[1] - lps[0] of proposal step k (block perm[k]) as
+                                          * formed at pyglm/regression.py:293-307 -- the change in log marginal likelihood (:343-378)
+                                          * plus log rho - log(1 - rho); NaN where rho is exactly 0 or 1 (the reference's 0 log 0) */
 } pgl_flip_t;
 int pgl_flip_kmax(void);                         /* pivots (scalar rows) per tableau update */
 int pgl_flip_window_blocks(int B);               /* blocks proposed per window */

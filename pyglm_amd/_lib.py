@@ -13,7 +13,7 @@ class FlipState(ctypes.Structure):   # pgl_flip_t
     _fields_ = [("M", c_p), ("ldj", c_l), ("strideM", c_l), ("nb", c_i), ("N", c_i), ("B", c_i),
                 ("perm", c_p), ("u", c_p), ("rho", c_p), ("c0", c_p), ("a", c_p), ("skip", c_p),
                 ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("G", c_p), ("Lws", c_p),
-                ("Ut", c_p), ("Wt", c_p), ("ldu", c_l), ("status", c_p), ("visit_order", c_i)]
+                ("Ut", c_p), ("Wt", c_p), ("ldu", c_l), ("status", c_p), ("visit_order", c_i), ("logodds", c_p)]
 
 
 class CholState(ctypes.Structure):   # pgl_chol_t
@@ -38,10 +38,14 @@ SIGNATURES = {
     "pgl_weighted_gram": [c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_p],
     "pgl_i8_plane_bytes": [c_i, c_i],
     "pgl_i8_residue_bytes": [c_i],
-    "pgl_i8_colmax": [c_p, c_l, c_i, c_i, c_p, c_p],
-    "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_max_planes": [],
+    "pgl_i8_min_planes": [c_i],
+    "pgl_i8_norm_bits": [c_i, c_i],
+    "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
+    "pgl_i8_scales": [c_p, c_p, c_l, c_i, c_i, c_p, c_p],
+    "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
     "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "pgl_flip_kmax": [],
@@ -55,6 +59,7 @@ SIGNATURES = {
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
+ABI_VERSION = 2
 _lib = None
 
 
@@ -76,8 +81,8 @@ def load():
         fn.argtypes = args
         fn.restype = (ctypes.c_char_p if name == "pgl_last_error" else ctypes.c_size_t if name in ("pgl_i8_plane_bytes", "pgl_i8_residue_bytes")
                       else ctypes.c_int)
-    if lib.pgl_abi_version() != 1:
-        raise PglError("libpyglm_hip.so ABI version %d != 1" % lib.pgl_abi_version())
+    if lib.pgl_abi_version() != ABI_VERSION:
+        raise PglError("libpyglm_hip.so ABI version %d != %d (rebuild: make -C pyglm_amd/csrc)" % (lib.pgl_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -12,6 +12,41 @@ void pgl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int pgl_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+int pgl_device_cus(int dev) {
+    static std::atomic<int> cus[PGL_MAX_DEVICES];
+    const int slot = dev & (PGL_MAX_DEVICES - 1);
+    int n = cus[slot].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[slot].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+int pgl_set_dynamic_lds(const void* fn, size_t bytes, PglPerDevice& flag) {
+    const int dev = pgl_device();
+    if (flag.done(dev)) return PGL_OK;
+    if (bytes > 160 * 1024) { pgl_set_error("LDS request %zu > 160 KiB", bytes); return PGL_ERR_ARG; }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", bytes, hipGetErrorString(e)); return PGL_ERR_HIP; }
+    flag.mark(dev);
+    return PGL_OK;
+}
+
+int pgl_grow_dynamic_lds(const void* fn, size_t bytes, PglPerDeviceSize& have) {
+    std::atomic<size_t>& cur = have.set[pgl_device() & (PGL_MAX_DEVICES - 1)];
+    if (bytes <= cur.load(std::memory_order_acquire)) return PGL_OK;
+    if (bytes > 160 * 1024) { pgl_set_error("LDS request %zu > 160 KiB", bytes); return PGL_ERR_ARG; }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", bytes, hipGetErrorString(e)); return PGL_ERR_HIP; }
+    cur.store(bytes, std::memory_order_release);
+    return PGL_OK;
+}
+
 // kernels' host launchers (other translation units)
 int pgl_k_philox_words(uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint32_t*, size_t, hipStream_t);
 int pgl_k_pg_draw(const double*, const double*, double*, size_t, uint64_t, uint64_t, uint64_t, hipStream_t);
@@ -27,15 +62,19 @@ int pgl_k_assemble_post(double*, long, long, const double*, const double*, long,
                         const double*, int, int, int, hipStream_t);
 size_t pgl_k_i8_plane_bytes(int, int);
 size_t pgl_k_i8_residue_bytes(int);
-int pgl_k_i8_colmax(const double*, long, int, int, double*, hipStream_t);
-int pgl_k_i8_planes(const double*, long, const double*, long, const double*, const double*, int8_t*, int, int, int, hipStream_t);
-int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, int, int, int, hipStream_t);
+int pgl_k_i8_max_planes(void);
+int pgl_k_i8_min_planes(int);
+int pgl_k_i8_nu(int, int);
+int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
+int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
+int pgl_k_i8_planes(const double*, long, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);
+int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, int, int, int, int, hipStream_t);
 int pgl_k_i8_crt(const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
 struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
-    int permuted;
+    int permuted; double* logodds;
 };
 int pgl_k_flip_apply(const PglFlipState&, int, int, int, hipStream_t);
 int pgl_k_flip_permute(const PglFlipState&, const double*, long, long, hipStream_t);
@@ -147,29 +186,42 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
 // ---- integer-MFMA Gram (what the engine uses at large shapes instead of pgl_weighted_gram)
 size_t pgl_i8_plane_bytes(int D, int T) { return pgl_k_i8_plane_bytes(D, T); }
 size_t pgl_i8_residue_bytes(int D) { return pgl_k_i8_residue_bytes(D); }
-int pgl_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, void* st) {
-    PGL_CHECK_ARG(V && out && T > 0 && ncol > 0 && ldv >= ncol);
-    return pgl_k_i8_colmax(V, ldv, T, ncol, out, ST(st));
+int pgl_i8_max_planes(void) { return pgl_k_i8_max_planes(); }
+int pgl_i8_min_planes(int T) { return pgl_k_i8_min_planes(T); }
+int pgl_i8_norm_bits(int nplanes, int T) { return pgl_k_i8_nu(nplanes, T); }
+#define PGL_CHECK_PLANES(np, T) PGL_CHECK_ARG((np) >= 1 && (np) <= pgl_k_i8_max_planes() && pgl_k_i8_nu((np), (T)) >= 8)
+int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* st) {
+    PGL_CHECK_ARG(X && amax && sumsq && T > 0 && D > 0 && G >= 1 && G <= 8 && ldx >= D && (Om == nullptr ? G == 1 : ldo >= G));
+    return pgl_k_i8_colstats(X, ldx, Om, ldo, T, D, G, amax, sumsq, ST(st));
 }
-int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* xmax, const double* wmax, void* planes, int T, int D, int G,
+int pgl_i8_scales(const double* amax, const double* sumsq, long ncols, int T, int nplanes, double* scale, void* st) {
+    PGL_CHECK_ARG(amax && sumsq && scale && ncols > 0 && T > 0);
+    PGL_CHECK_PLANES(nplanes, T);
+    return pgl_k_i8_scales(amax, sumsq, ncols, T, nplanes, scale, ST(st));
+}
+int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
                   void* st) {
-    PGL_CHECK_ARG(X && xmax && planes && T > 0 && D > 0 && G > 0 && ldx >= D && (Om == nullptr || (wmax != nullptr && ldo >= G)));
+    PGL_CHECK_ARG(X && scale && planes && T > 0 && D > 0 && G > 0 && ldx >= D && (Om == nullptr || ldo >= G));
     PGL_CHECK_ARG(Om != nullptr || G == 1);
-    return pgl_k_i8_planes(X, ldx, Om, ldo, xmax, wmax, static_cast<int8_t*>(planes), T, D, G, ST(st));
+    PGL_CHECK_PLANES(nplanes, T);
+    return pgl_k_i8_planes(X, ldx, Om, ldo, scale, static_cast<int8_t*>(planes), T, D, G, nplanes, ST(st));
 }
-int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, void* st) {
+int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, int nplanes, void* st) {
     PGL_CHECK_ARG(planes_x && planes_wx && residues && T > 0 && D > 0 && G > 0);
-    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), T, D, G, ST(st));
+    PGL_CHECK_PLANES(nplanes, T);
+    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), T, D, G,
+                         nplanes, ST(st));
 }
-int pgl_i8_crt(const void* residues, const double* xmax, const double* wmax, double* J, long ldj, long strideJ, int T, int D, int G, int accumulate,
-               void* st) {
-    PGL_CHECK_ARG(residues && xmax && wmax && J && T > 0 && D > 0 && G > 0 && ldj >= D);
-    return pgl_k_i8_crt(static_cast<const int8_t*>(residues), xmax, wmax, J, ldj, strideJ, T, D, G, accumulate, ST(st));
+int pgl_i8_crt(const void* residues, const double* scale_x, const double* scale_wx, double* J, long ldj, long strideJ, int T, int D, int G,
+               int nplanes, int accumulate, void* st) {
+    PGL_CHECK_ARG(residues && scale_x && scale_wx && J && T > 0 && D > 0 && G > 0 && ldj >= D);
+    PGL_CHECK_PLANES(nplanes, T);
+    return pgl_k_i8_crt(static_cast<const int8_t*>(residues), scale_x, scale_wx, J, ldj, strideJ, D, G, nplanes, accumulate, ST(st));
 }
 
 static PglFlipState to_state(const pgl_flip_t* s) {
     return PglFlipState{s->M, s->ldj, s->strideM, s->nb, s->N, s->B, s->perm, s->u, s->rho, s->c0, s->a, s->skip,
-                        s->d_idx, s->d_sign, s->d_cnt, s->batch_k, s->G, s->Lws, s->Ut, s->Wt, s->ldu, s->status, s->visit_order};
+                        s->d_idx, s->d_sign, s->d_cnt, s->batch_k, s->G, s->Lws, s->Ut, s->Wt, s->ldu, s->status, s->visit_order, s->logodds};
 }
 int pgl_flip_kmax(void) { return pgl_k_flip_kmax(); }
 int pgl_flip_window_blocks(int B) { return pgl_k_flip_window_blocks(B); }

@@ -3,12 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 #define PGL_OK 0
 #define PGL_ERR_ARG 1
 #define PGL_ERR_HIP 2
 
 void pgl_set_error(const char* fmt, ...);
+
+// Library state is kept PER DEVICE (a process may drive several GPUs, one engine each): the dynamic-LDS attribute of a kernel belongs to the
+// device it was set on, and so do the CU count and the scheduler scratch of the persistent launches.
+constexpr int PGL_MAX_DEVICES = 32;
+int pgl_device();                          // current HIP device (0 if the query fails)
+int pgl_device_cus(int dev);               // compute units of `dev`, cached
+struct PglPerDevice {                      // "done once on this device" flags, lock-free
+    std::atomic<uint32_t> mask{0};
+    bool done(int dev) const { return (mask.load(std::memory_order_acquire) >> (dev & 31)) & 1u; }
+    void mark(int dev) { mask.fetch_or(1u << (dev & 31), std::memory_order_release); }
+};
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize = bytes) once per (kernel, device)
+int pgl_set_dynamic_lds(const void* fn, size_t bytes, PglPerDevice& flag);
+// same for a kernel whose request varies between launches: raised whenever a launch needs more than was set on this device
+struct PglPerDeviceSize { std::atomic<size_t> set[PGL_MAX_DEVICES]; };
+int pgl_grow_dynamic_lds(const void* fn, size_t bytes, PglPerDeviceSize& have);
 
 #define PGL_CHECK_ARG(cond)                                                              \
     do {                                                                                 \

@@ -45,6 +45,7 @@ struct FlipArgs {
     int* status;                                 // [nb] sticky error flags (1 = non-PD block met)
     int permuted;                                // 1: tableau rows/columns are in VISIT order (position k holds block perm[k]; bias, h last)
     int c_begin;                                 // first column the pivot-row gather has to produce (trailing-only window updates)
+    double* logodds;                             // [nb][N] or null: lps[1] - lps[0] per proposal step (parity checks)
 };
 
 __device__ __forceinline__ double tab_get(const double* M, long ld, int i, int j) { return i >= j ? M[(long)i * ld + j] : M[(long)j * ld + i]; }
@@ -104,15 +105,18 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             const double dml = (am ? 0.5 * logdet : -0.5 * logdet) + 0.5 * quad + g.c0[(long)n * N + m];
             const double rho = g.rho[(long)n * N + m];
             int v;
+            double lo = __builtin_nan("");
             if (rho == 0.0 || rho == 1.0) {
                 v = 0;   // reference :298/:307: 0*log(0) = NaN reaches sample_discrete_from_log, which then returns 0
             } else {
                 const double d = dml + log(rho) - log(1.0 - rho);       // lps[1] - lps[0]
+                lo = d;
                 const double mx = d > 0.0 ? d : 0.0;
                 const double e0 = exp(-mx), e1 = exp(d - mx);           // exp(lps - max)
                 const double uu = g.u[(long)n * N + k0 + k];
                 v = (uu * (e0 + e1) > e0) ? 1 : 0;                      // cum = [e0, e0+e1]; count(r > cum)
             }
+            if (g.logodds) g.logodds[(long)n * N + k0 + k] = lo;
             s_flip = (v != am);
             s_sign = v ? 1 : -1;                 // forward sweep when switching on
             s_flipped[k] = (v != am) ? (v ? 1 : -1) : 0;
@@ -525,18 +529,11 @@ size_t pgl_k_flip_lds_decide(int B, int R) {
     return (2 * (size_t)nl * B + 2 * (size_t)B * B + B) * sizeof(double);
 }
 
-static int set_lds(const void* fn, size_t bytes) {
-    if (bytes > 160 * 1024) { pgl_set_error("LDS request %zu > 160 KiB", bytes); return PGL_ERR_ARG; }
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGL_ERR_HIP; }
-    return PGL_OK;
-}
-
 struct PglFlipState {
     double* M; long ldj; long strideM; int nb, N, B;
     const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
-    int permuted;
+    int permuted; double* logodds;
 };
 
 int pgl_k_flip_window_blocks(int B) {
@@ -557,10 +554,10 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
         r0 = ((window + 1) * R_ * s.B) & ~1;
     }
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R_, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, r0};
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, r0, s.logodds};
     const size_t lds_inv = ((size_t)KMAX + 128 * 129) * sizeof(double);
-    static bool once = false;
-    if (!once) { int rc = set_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv); if (rc) return rc; once = true; }
+    static PglPerDevice once;
+    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv, once)) return rc;
     const int Md = Md_;
     if (!have_G && max_pivots > KB2) {
         if (max_pivots > 2 * KB2) { pgl_set_error("flip_apply: %d pivots per call (max %d)", max_pivots, 2 * KB2); return PGL_ERR_ARG; }
@@ -622,7 +619,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
 
 int pgl_k_flip_permute(const PglFlipState& s, const double* J, long ldjs, long strideJ, hipStream_t st) {
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, 0, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, 1, 0};
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, 1, 0, s.logodds};
     hipLaunchKernelGGL(permute_tableau_kernel, dim3(1, s.N + 2, s.nb), dim3(256), (size_t)s.N * sizeof(int), st, g, J, ldjs, strideJ);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
@@ -632,10 +629,10 @@ int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
     const int R = pgl_k_flip_window_blocks(s.B);
     if (R < 1) { pgl_set_error("B=%d exceeds the window capacity %d", s.B, KWIN); return PGL_ERR_ARG; }
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
-               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, 0};
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, 0, s.logodds};
     const size_t lds = pgl_k_flip_lds_decide(s.B, R);
-    static size_t lds_set = 0;
-    if (lds > lds_set) { int rc = set_lds(reinterpret_cast<const void*>(decide_kernel), lds); if (rc) return rc; lds_set = lds; }
+    static PglPerDeviceSize lds_set;                      // the request depends on (B, R): raised per device when a launch needs more
+    if (int rc = pgl_grow_dynamic_lds(reinterpret_cast<const void*>(decide_kernel), lds, lds_set)) return rc;
     hipLaunchKernelGGL(decide_kernel, dim3(s.nb), dim3(1024), lds, st, g, window);
     PGL_CHECK_LAUNCH();
     return PGL_OK;

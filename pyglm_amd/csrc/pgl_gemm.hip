@@ -707,13 +707,9 @@ int launch(const PglGemmArgs& a, hipStream_t st) {
     if constexpr (!WEIGHTED && STAGES == 2 && !CINIT) {
         if (a.beta == 1.0 && (a.alpha == 1.0 || a.alpha == -1.0)) return launch<WM, WN, WZ, WEIGHTED, STAGES, true>(a, st);
     }
-    static bool attr_set = false;
+    static PglPerDevice attr_set;
     auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED, STAGES, CINIT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", C::LDS_BYTES, hipGetErrorString(e)); return PGL_ERR_HIP; }
-        attr_set = true;
-    }
+    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, attr_set)) return rc;
     const int ntm = (a.M + C::BM - 1) / C::BM, ntn = (a.N + C::BN - 1) / C::BN;
     const long ntiles = a.tri ? (long)ntm * (ntm + 1) / 2 : (long)ntm * ntn;
     const long total = ntiles * a.nbatch;
@@ -726,16 +722,22 @@ int launch(const PglGemmArgs& a, hipStream_t st) {
     return PGL_OK;
 }
 
-// scheduler scratch of the persistent launches: a ring of 8-counter slots (32 B each), allocated once on first use.
-// (The only device memory the library itself owns; every data buffer belongs to the caller.)
+// scheduler scratch of the persistent launches: per device a ring of 8-counter slots (32 B each, 8 KiB in all), allocated on first use
+// on that device.  (The only device memory the library itself owns -- documented in include/pyglm_hip.h; every data buffer belongs to
+// the caller.)
 static int* sched_slot(hipStream_t st) {
-    static int* base = nullptr;
-    static unsigned next = 0;
+    static std::atomic<int*> bases[PGL_MAX_DEVICES];
+    static std::atomic<unsigned> next{0};
     constexpr unsigned SLOTS = 256;
+    std::atomic<int*>& b = bases[pgl_device() & (PGL_MAX_DEVICES - 1)];
+    int* base = b.load(std::memory_order_acquire);
     if (!base) {
-        if (hipMalloc(reinterpret_cast<void**>(&base), SLOTS * 8 * sizeof(int)) != hipSuccess) { base = nullptr; return nullptr; }
+        int* fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&fresh), SLOTS * 8 * sizeof(int)) != hipSuccess) return nullptr;
+        if (b.compare_exchange_strong(base, fresh, std::memory_order_acq_rel)) base = fresh;
+        else (void)hipFree(fresh);                     // another host thread got there first
     }
-    int* slot = base + (size_t)(next++ % SLOTS) * 8;
+    int* slot = base + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % SLOTS) * 8;
     if (hipMemsetAsync(slot, 0, 8 * sizeof(int), st) != hipSuccess) return nullptr;
     return slot;
 }
@@ -743,19 +745,11 @@ static int* sched_slot(hipStream_t st) {
 template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA>
 int launch_persistent(const PglGemmArgs& a0, hipStream_t st) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
-    static bool attr_set = false;
-    static int n_cu = 0;
+    static PglPerDevice attr_set;
     auto kern = gemm_tn_f64_persistent<WM, WN, WZ, WEIGHTED, STAGES, DMA>;
     constexpr size_t lds = C::LDS_BYTES + 16;     // + the work ticket
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return PGL_ERR_HIP; }
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-        attr_set = true;
-    }
+    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set)) return rc;
+    const int n_cu = pgl_device_cus(pgl_device());
     const int ntm = (a0.M + C::BM - 1) / C::BM, ntn = (a0.N + C::BN - 1) / C::BN;
     const long total = (a0.tri ? (long)ntm * (ntm + 1) / 2 : (long)ntm * ntn) * a0.nbatch;
     if (total <= 0) return PGL_OK;
@@ -770,17 +764,9 @@ int launch_persistent(const PglGemmArgs& a0, hipStream_t st) {
 }
 
 static int launch_gram_fine(const PglGemmArgs& a0, hipStream_t st) {
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fine_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute(LDS=%zu): %s", F_LDS, hipGetErrorString(e)); return PGL_ERR_HIP; }
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-        attr_set = true;
-    }
+    static PglPerDevice attr_set;
+    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(gram_fine_persistent), F_LDS, attr_set)) return rc;
+    const int n_cu = pgl_device_cus(pgl_device());
     const int ntm = (a0.M + 127) / 128;
     const long total = (long)ntm * (ntm + 1) / 2 * a0.nz_total;
     if (total <= 0) return PGL_OK;
@@ -811,12 +797,7 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             // launches that cannot give every CU two 8-wave items (few neurons: small models, thin shards) run as 4-wave workgroups,
             // one neuron each, two per CU: twice the items, and 53 vs 29 TFLOP/s at D = 640 with 16 neurons; at full size the
             // 8-wave pipeline (two neurons share every staged X tile) is 5 % faster
-            static int n_cu = 0;
-            if (n_cu == 0) {
-                int dev = 0;
-                (void)hipGetDevice(&dev);
-                if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-            }
+            const int n_cu = pgl_device_cus(pgl_device());
             const long ntm = (a.M + 127) / 128;
             if (variant == 3 && ntm * (ntm + 1) / 2 * a.nbatch < 2L * n_cu) return launch_gram_fine(a, st);
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);

@@ -1,19 +1,25 @@
 // The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (the engine's choice at large shapes,
-// the fp64 kernel of pgl_gemm.hip otherwise).  The fp64 operands are scaled column by column to beta-bit integers (beta = 50 up to
-// T = 112 000 time bins, 49 beyond),
-//     A[t][i] = rint(x_ti 2^eA_i),      B_n[t][j] = rint(omega_nt x_tj 2^fB_nj),
-// the integer Gram S = A'B_n is computed modulo 15 pairwise coprime moduli p <= 256 -- one int8 GEMM per modulus on residues that fit
-// a signed byte, int32 accumulation (re-reduced mod p every 128 000 time bins) -- and reconstructed exactly by the Chinese remainder
-// theorem (|S| <= T 2^(2 beta) < prod(p)/2 = 2^116.78);  J = S 2^-(eA_i + fB_nj).  The only approximation is the rounding of the operands
-// to beta-bit fixed point per column: error ~1e-15 |a_i||b_j|, the level of an fp64 product at K = 1e5 (tools/ozaki2_accuracy.py).
+// the fp64 kernel of pgl_gemm.hip otherwise).  The fp64 operands are scaled COLUMN BY COLUMN to integers,
+//     A[t][i] = rint(x_ti sA_i),      B_n[t][j] = rint((omega_nt x_tj) sB_nj),
+// with power-of-two scales chosen from each column's Euclidean norm and largest element (i8_colstats_kernel, i8_scales_kernel):
+//     |A_i|_2, |B_nj|_2 in [2^(nu-1), 2^nu)   unless the largest element would reach 2^50 (then that bound decides),
+// so that by Cauchy-Schwarz every entry of the integer Gram S = A'B_n obeys |S_ij| <= |A_i||B_nj| < prod(p)/2 for the K <= 15 pairwise
+// coprime moduli p <= 256 in use (nu = nu(K, T): 50 / 54 / 58 for K = 13 / 14 / 15).  S is computed modulo each p -- one int8 GEMM per
+// modulus on residues that fit a signed byte, int32 accumulation (re-reduced mod p every 128 000 time bins) -- and reconstructed exactly by
+// the Chinese remainder theorem;  J_ij = S_ij / (sA_i sB_nj).  The only approximation is the rounding of the operands to integers: with
+// independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_nj|^-2) / 12) |a_i||b_nj|, i.e. <= 7.3e-16 |a_i||b_j|
+// at K = 13, <= 4.6e-17 at K = 14 for ordinary columns (a column whose norm is one outlier element is held at 2^49..2^50 by the element
+// bound at every K) -- for ANY data: the precision is pinned to the column norms, not to the column maxima.
 //
-//   i8_planes_kernel   fp64 (t-major) -> 15 residue planes in BLOCKED layout [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once
+//   i8_colstats_kernel max_t |v| and sum_t v^2 per column of X (once per data set) and of omega_g X (per neuron and sweep), deterministic
+//   i8_scales_kernel   the power-of-two scale of every column from those statistics
+//   i8_planes_kernel   fp64 (t-major) -> K residue planes in BLOCKED layout [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once
 //                      per data set), PB[g] for omega_g X (per neuron, per sweep); one pass over X per group of neurons; residues by four
 //                      fp64 operations each (no integer division)
 //   i8_gram_kernel     R[g][q] = (PA[q] PB[g][q]') mod p_q on lower 256 x 256 tiles (v_mfma_i32_16x16x64_i8; 8 waves = 2 x 4, wave tile
 //                      128 x 64; K tiles DMA-staged into 4 LDS stages, one contiguous KiB per request, 16-byte chunks XOR-swizzled:
 //                      conflict-free ds_read_b128); persistent workgroups, per-XCD work lists in a clustered tile order (L2 sharing)
-//   i8_crt_kernel      15 residues -> mixed-radix digits (Garner) -> fp64 by Horner -> scaled into the lower triangle of J
+//   i8_crt_kernel      K residues -> mixed-radix digits (Garner) -> fp64 by Horner -> unscaled into the lower triangle of J
 #include "pgl_common.h"
 #include <cmath>
 #include <type_traits>
@@ -48,40 +54,80 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__device__ __forceinline__ int scale_exp(double maxabs, int beta) {       // e with |v 2^e| < 2^beta for every |v| <= maxabs
-    if (!(maxabs > 0.0)) return 0;
-    int ex;
-    (void)frexp(maxabs, &ex);                                    // maxabs = m 2^ex, m in [0.5, 1)
-    return beta - ex;
+constexpr int ELEM_BITS = 50;          // |scaled element| < 2^50: the residue trick below needs |v| + 1.5 2^52 to stay below 2^53
+
+// ------------------------------------------------------------------ column statistics of V = X (Om == null) or omega_g X
+// amax[g][c] = max_t |v_tc|, ss[g][c] = sum_t v_tc^2 for the G <= 8 weight columns of a group in ONE pass over X.  A workgroup owns 16
+// columns for all T (16 x 64 threads: column = tid % 16, time lane = tid / 16), so the sums are formed in a fixed order -- no atomics:
+// the scales, and with them every bit of J, do not depend on launch timing.  A NaN / inf sticks in amax (the Gram of that column is
+// then NaN, as on the fp64 kernel).
+constexpr int CS_COLS = 16, CS_LANES = 64, CS_G = 8;
+__global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const double* __restrict__ X, long ldx, const double* __restrict__ Om,
+                                                                        long ldo, int T, int D, int G, double* __restrict__ amax,
+                                                                        double* __restrict__ ss) {
+    __shared__ double red[2][CS_LANES][CS_COLS + 1];
+    const int cl = threadIdx.x % CS_COLS, tl = threadIdx.x / CS_COLS, c = blockIdx.x * CS_COLS + cl;
+    double m[CS_G], q[CS_G];
+#pragma unroll
+    for (int g = 0; g < CS_G; ++g) { m[g] = 0.0; q[g] = 0.0; }
+    if (c < D)
+        for (int t = tl; t < T; t += CS_LANES) {
+            const double x = X[(long)t * ldx + c];
+#pragma unroll
+            for (int g = 0; g < CS_G; ++g)
+                if (g < G) {
+                    const double v = Om ? x * Om[(long)t * ldo + g] : x;       // the same product the planes kernel rounds
+                    const double av = fabs(v);
+                    m[g] = av > m[g] || av != av ? av : m[g];
+                    q[g] = fma(v, v, q[g]);
+                }
+        }
+#pragma unroll
+    for (int g = 0; g < CS_G; ++g) {
+        if (g >= G) break;
+        __syncthreads();
+        red[0][tl][cl] = m[g];
+        red[1][tl][cl] = q[g];
+        __syncthreads();
+        if (tl == 0 && c < D) {                  // one thread per column folds the 64 time lanes in order
+            double mm = 0.0, qq = 0.0;
+            for (int k = 0; k < CS_LANES; ++k) {
+                const double v = red[0][k][cl];
+                mm = v > mm || v != v ? v : mm;
+                qq += red[1][k][cl];
+            }
+            amax[(long)g * D + c] = mm;
+            ss[(long)g * D + c] = qq;
+        }
+    }
 }
 
-// ------------------------------------------------------------------ column maxima of |X| (per data set) and of omega (per neuron)
-__global__ __launch_bounds__(256) void colmax_kernel(const double* __restrict__ V, long ldv, int T, int ncol, double* __restrict__ out) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    __shared__ double red[4][64];
-    double m = 0.0;
-    if (c < ncol)
-        for (int t = blockIdx.y * 4 + part; t < T; t += gridDim.y * 4) {
-            const double v = fabs(V[(long)t * ldv + c]);
-            m = v > m || v != v ? v : m;                 // a NaN sticks (fmax would drop it): the Gram of that column is then NaN, as in fp64
-        }
-    red[part][threadIdx.x & 63] = m;
-    __syncthreads();
-    if (part == 0 && c < ncol) {
-        for (int k = 1; k < 4; ++k) { const double v = red[k][threadIdx.x]; m = v > m || v != v ? v : m; }
-        // non-negative doubles order like their bit patterns (+inf and NaN above every finite value)
-        atomicMax(reinterpret_cast<unsigned long long*>(out + c), (unsigned long long)__double_as_longlong(m));
+// scale[k] = 2^e, e the largest exponent with  sqrt(ss) 2^e < 2^nu  and  amax 2^e < 2^ELEM_BITS  (1 for an empty column, NaN for a
+// non-finite one)
+__global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict__ amax, const double* __restrict__ ss, long n, int nu,
+                                                        double* __restrict__ scale) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double a = amax[k], nrm = sqrt(ss[k]) * (1.0 + 1e-12);        // (summation error of ss: never let it loosen the bound)
+    double s = 1.0;
+    if (!(a < HUGE_VAL) || !(nrm < HUGE_VAL)) s = __builtin_nan("");
+    else if (a > 0.0) {
+        int exa, exn;
+        (void)frexp(a, &exa);                                            // a = m 2^exa, m in [0.5, 1)
+        (void)frexp(nrm > a ? nrm : a, &exn);
+        const int e = min(ELEM_BITS - exa, nu - exn);
+        s = ldexp(1.0, e);
     }
+    scale[k] = s;
 }
 
 // ------------------------------------------------------------------ fp64 -> residue planes
 struct PlaneArgs {
     const double* X; long ldx;            // [T][ldx]
     const double* Om; long ldo;           // [T][ldo] weights of the group's neurons (null: unweighted, one "neuron")
-    const double* xmax;                   // [D]
-    const double* wmax;                   // [G] (weighted only)
-    int8_t* P;                            // [G][NP] planes of Dq * Kp bytes, blocked [Dq / 16][Kp / 64][16][64]
-    int T, D, Dq; long Kp; int beta;
+    const double* scale;                  // [G][D] fixed-point scale of column d of neuron g (i8_scales_kernel)
+    int8_t* P;                            // [G][np] planes of Dq * Kp bytes, blocked [Dq / 16][Kp / 64][16][64]
+    int T, D, Dq; long Kp; int np;
 };
 
 // A workgroup converts 256 time bins x 16 columns (one row block, four K tiles) of X, staged ONCE in LDS, for all G neurons of the group.
@@ -116,7 +162,7 @@ __global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a, int G) {
         if (a.Om) oms[tid] = t0 + tid < a.T ? a.Om[(long)(t0 + tid) * a.ldo + gz] : 0.0;
         __syncthreads();
         if (!live) continue;
-        const double scale = d < a.D ? ldexp(1.0, scale_exp(a.Om ? a.wmax[gz] * a.xmax[d] : a.xmax[d], a.beta)) : 0.0;
+        const double scale = d < a.D ? a.scale[(long)gz * a.D + d] : 0.0;
         double v[16], vm[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -124,29 +170,31 @@ __global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a, int G) {
             v[k] = rint((a.Om ? x * oms[tb + k] : x) * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
             vm[k] = v[k] + MAGIC;                                   // exact: integers below 2^53
         }
-        int8_t* dst = dst0 + (long)gz * NP * plane;
+        int8_t* dst = dst0 + (long)gz * a.np * plane;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            unsigned b[16];
-            if (q == 0) {
+            if (q < a.np) {                                  // (uniform: the launch's number of moduli)
+                unsigned b[16];
+                if (q == 0) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) b[k] = (unsigned)__double2loint(vm[k]);      // mod 256: the low byte of the integer itself
-            } else {
-                const double pd = (double)MT.p[q], ip = 1.0 / pd;
+                    for (int k = 0; k < 16; ++k) b[k] = (unsigned)__double2loint(vm[k]);      // mod 256: the low byte of the integer itself
+                } else {
+                    const double pd = (double)MT.p[q], ip = 1.0 / pd;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const double qq = (v[k] * ip + MAGIC) - MAGIC;
-                    b[k] = (unsigned)__double2loint(fma(-pd, qq, vm[k]));
+                    for (int k = 0; k < 16; ++k) {
+                        const double qq = (v[k] * ip + MAGIC) - MAGIC;
+                        b[k] = (unsigned)__double2loint(fma(-pd, qq, vm[k]));
+                    }
                 }
-            }
-            v4i out;
+                v4i out;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned lo = __builtin_amdgcn_perm(b[4 * j + 1], b[4 * j], 0x0c0c0400u);
-                const unsigned hi = __builtin_amdgcn_perm(b[4 * j + 3], b[4 * j + 2], 0x0c0c0400u);
-                out[j] = (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned lo = __builtin_amdgcn_perm(b[4 * j + 1], b[4 * j], 0x0c0c0400u);
+                    const unsigned hi = __builtin_amdgcn_perm(b[4 * j + 3], b[4 * j + 2], 0x0c0c0400u);
+                    out[j] = (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                }
+                *reinterpret_cast<v4i*>(dst + (long)q * plane) = out;
             }
-            *reinterpret_cast<v4i*>(dst + (long)q * plane) = out;
         }
     }
 }
@@ -159,10 +207,10 @@ constexpr int KCH = 2000;                                    // K tiles between 
 constexpr int SB = 6, CH = 32;                               // clustered tile order: super-blocks of SB x SB tiles; work-list chunk per XCD
 
 struct GramArgs {
-    const int8_t* PA;                     // [NP] planes
-    const int8_t* PB;                     // [G][NP] planes
-    int8_t* R;                            // [G][NP][Dq][Dq]
-    int Dq; long Kp; int G;
+    const int8_t* PA;                     // [np] planes
+    const int8_t* PB;                     // [G][np] planes
+    int8_t* R;                            // [G][np][Dq][Dq]
+    int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
 };
 
@@ -203,7 +251,7 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
     const int wm = wave >> 2, wn = wave & 3;
     const long plane = (long)g.Dq * g.Kp;
     const int8_t* A = g.PA + (long)q * plane;
-    const int8_t* B = g.PB + ((long)gz * NP + q) * plane;
+    const int8_t* B = g.PB + ((long)gz * g.np + q) * plane;
     const int nkt = (int)(g.Kp / BKB);
 
     // DMA: per K tile 512 rows x 64 B = 32 requests of 1 KiB (16 rows = one row block of the blocked plane layout: contiguous in memory,
@@ -311,7 +359,7 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant last requests must have landed before the LDS is reused
     // epilogue: reduce mod p and store bytes.  C/D layout of 16x16 i32: col = lane & 15, row = 4 (lane >> 4) + reg
-    int8_t* R = g.R + ((long)gz * NP + q) * g.Dq * g.Dq;
+    int8_t* R = g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -332,7 +380,7 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
     int* ticket = reinterpret_cast<int*>(lds + NST * STAGE_BYTES);
     const int ntm = g.Dq / TM;
     const int ntiles = ntm * (ntm + 1) / 2;
-    const int total = ntiles * NP * g.G;
+    const int total = ntiles * g.np * g.G;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
@@ -357,45 +405,47 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
         if (ticket[0] < 0) break;
         const int pair = __builtin_amdgcn_readfirstlane(ticket[1]);
         const int tm = __builtin_amdgcn_readfirstlane(ticket[2]), tn = __builtin_amdgcn_readfirstlane(ticket[3]);
-        i8_gram_item(g, pair / NP, pair % NP, tm, tn, lds);
+        i8_gram_item(g, pair / g.np, pair % g.np, tm, tn, lds);
     }
 }
 
 // ------------------------------------------------------------------ CRT reconstruction into J
 struct CrtArgs {
-    const int8_t* R;                      // [G][NP][Dq][Dq]
-    const double* xmax; const double* wmax;
+    const int8_t* R;                      // [G][np][Dq][Dq]
+    const double* sA; const double* sB;   // scales: [D], [G][D]
     double* J; long ldj; long strideJ;    // [G] slots
-    int D, Dq, G, accumulate, beta;
+    int D, Dq, G, accumulate, np;
 };
 
 __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, gz = blockIdx.z;
     if (j > i || i >= a.D) return;
-    const int8_t* R = a.R + ((long)gz * NP) * a.Dq * a.Dq + (long)i * a.Dq + j;
+    const int8_t* R = a.R + ((long)gz * a.np) * a.Dq * a.Dq + (long)i * a.Dq + j;
     int v[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) v[q] = (int)R[(long)q * a.Dq * a.Dq];
+    for (int q = 0; q < NP; ++q) v[q] = q < a.np ? (int)R[(long)q * a.Dq * a.Dq] : 0;
     // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...;  digit q =
     // (r_q - sum_{k<q} v_k (p_0..p_{k-1} mod p_q)) (p_0..p_{q-1})^-1 mod p_q: the sum is accumulated unreduced (14 terms of at most
     // 128 * 128), so a digit costs q multiply-adds and ONE reduction instead of q reductions
 #pragma unroll
     for (int q = 1; q < NP; ++q) {
-        const int p = MT.p[q];
-        int u = v[q];
+        if (q < a.np) {
+            const int p = MT.p[q];
+            int u = v[q];
 #pragma unroll
-        for (int k = 0; k < q; ++k) u -= v[k] * MT.w[k][q];                          // |u| < 2^18
-        int t = u * MT.pinv[q] % p;                                                   // < 2^26 in magnitude
-        if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
-        v[q] = t;
+            for (int k = 0; k < q; ++k) u -= v[k] * MT.w[k][q];                          // |u| < 2^18
+            int t = u * MT.pinv[q] % p;                                                   // < 2^26 in magnitude
+            if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
+            v[q] = t;
+        }
     }
-    double s = (double)v[NP - 1];
+    double s = 0.0;
 #pragma unroll
-    for (int q = NP - 2; q >= 0; --q) s = s * (double)MT.p[q] + (double)v[q];
-    const int e = scale_exp(a.xmax[i], a.beta) + scale_exp(a.wmax[gz] * a.xmax[j], a.beta);
-    // non-finite data (a diverged chain): NaN out, as the fp64 product would give -- never a finite number made of garbage residues
-    const bool finite = a.xmax[i] < HUGE_VAL && a.xmax[j] < HUGE_VAL && a.wmax[gz] < HUGE_VAL;
-    const double val = finite ? ldexp(s, -e) : __builtin_nan("");
+    for (int q = NP - 1; q >= 0; --q)
+        if (q < a.np) s = s * (double)MT.p[q] + (double)v[q];
+    // non-finite data (a diverged chain): the scale of that column is NaN and so is every entry it takes part in, as the fp64 product
+    // would give -- never a finite number made of garbage residues.  Two divisions: the product of two scales may overflow.
+    const double val = (s / a.sA[i]) / a.sB[(long)gz * a.D + j];
     double* dst = a.J + (long)gz * a.strideJ + (long)i * a.ldj + j;
     *dst = a.accumulate ? *dst + val : val;
 }
@@ -406,13 +456,21 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
 // time bins per plane row: a multiple of the 64-byte K tile, at least four tiles (the Gram pipeline keeps three requested ahead)
 static long pgl_i8_kp(int T) { const long k = ((long)T + 63) / 64 * 64; return k < 256 ? 256 : k; }
 
-// bits of the scaled operands: the largest beta <= 50 with T 2^(2 beta) < prod(p) / 2, so that the CRT range holds the integer Gram for
-// any data (50 up to T = 112 000, 49 up to 451 000, ...)
-static int pgl_i8_beta(int T) {
+// nu(K, T): the columns' integer norms are kept below 2^nu, the largest integer with (2^nu (1 + 1e-9) + sqrt(T)/2 + 1)^2 <= prod(p_0..p_{K-1}) / 2
+// (rounding a column to integers adds at most sqrt(T)/2 to its norm), so |S_ij| <= |A_i||B_j| stays inside the symmetric CRT range
+int pgl_k_i8_nu(int nplanes, int T) {
     double l2 = 0.0;
-    for (int q = 0; q < NP; ++q) l2 += std::log2((double)MT.p[q]);
-    const int b = (int)std::floor((l2 - 1.0 - std::log2((double)(T < 1 ? 1 : T))) * 0.5 - 1e-9);
-    return b < 50 ? b : 50;
+    for (int q = 0; q < nplanes && q < NP; ++q) l2 += std::log2((double)MT.p[q]);
+    const double lim = (std::exp2((l2 - 1.0) * 0.5) - 0.5 * std::sqrt((double)(T < 1 ? 1 : T)) - 1.0) / (1.0 + 1e-9);
+    if (!(lim >= 2.0)) return 0;
+    return (int)std::floor(std::log2(lim) - 1e-12);
+}
+int pgl_k_i8_max_planes(void) { return NP; }
+// fewest moduli that keep the rounding error of the scaled operands at the fp64 level: column norms >= 2^49 need nu >= 50
+int pgl_k_i8_min_planes(int T) {
+    for (int k = 1; k <= NP; ++k)
+        if (pgl_k_i8_nu(k, T) >= 50) return k;
+    return NP + 1;
 }
 
 size_t pgl_k_i8_plane_bytes(int D, int T) {
@@ -424,54 +482,54 @@ size_t pgl_k_i8_residue_bytes(int D) {
     return (size_t)NP * Dq * Dq;
 }
 
-// column maxima of |V| (out must be zero-filled by the caller: maxima are merged with atomicMax)
-int pgl_k_i8_colmax(const double* V, long ldv, int T, int ncol, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(colmax_kernel, dim3((ncol + 63) / 64, 64), dim3(256), 0, st, V, ldv, T, ncol, out);
+int pgl_k_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* ss, hipStream_t st) {
+    if (G > CS_G) { pgl_set_error("i8 colstats: %d weight columns per call (max %d)", G, CS_G); return PGL_ERR_ARG; }
+    hipLaunchKernelGGL(i8_colstats_kernel, dim3((D + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, st, X, ldx, Om, ldo, T, D, G, amax, ss);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_i8_scales(const double* amax, const double* ss, long n, int T, int nplanes, double* scale, hipStream_t st) {
+    const int nu = pgl_k_i8_nu(nplanes, T);
+    if (nu < 8) { pgl_set_error("i8 scales: %d moduli leave no room for T = %d", nplanes, T); return PGL_ERR_ARG; }
+    hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amax, ss, n, nu, scale);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
 
 // residue planes of X (Om == null, G = 1) or of omega_g X for the G weight columns Om[:, 0..G)
-int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* xmax, const double* wmax, int8_t* P, int T, int D, int G,
+int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, int8_t* P, int T, int D, int G, int nplanes,
                     hipStream_t st) {
     const int Dq = (D + 255) / 256 * 256;
     const long Kp = pgl_i8_kp(T);
-    PlaneArgs a{X, ldx, Om, ldo, xmax, wmax, P, T, D, Dq, Kp, pgl_i8_beta(T)};
+    PlaneArgs a{X, ldx, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
     hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + PT_T - 1) / PT_T), Dq / PT_D), dim3(256), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
 
-int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, int G, hipStream_t st) {
+int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, int G, int nplanes, hipStream_t st) {
     const int Dq = (D + 255) / 256 * 256;
     const long Kp = pgl_i8_kp(T);
-    static bool attr = false;
-    static int n_cu = 0;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(i8_gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GRAM_LDS);
-        if (e != hipSuccess) { pgl_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGL_ERR_HIP; }
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-        attr = true;
-    }
+    static PglPerDevice attr;
+    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel), GRAM_LDS, attr)) return rc;
+    const int n_cu = pgl_device_cus(pgl_device());
     const int ntm = Dq / TM, ntiles = ntm * (ntm + 1) / 2;
-    const long total = (long)ntiles * NP * G;
+    const long total = (long)ntiles * nplanes * G;
     if (total <= 0) return PGL_OK;
     if (total > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
-    GramArgs g{PA, PB, R, Dq, Kp, G, pgl_sched_slot(st)};
+    GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, pgl_sched_slot(st)};
     if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
     hipLaunchKernelGGL(i8_gram_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), GRAM_LDS, st, g);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
 
-int pgl_k_i8_crt(const int8_t* R, const double* xmax, const double* wmax, double* J, long ldj, long strideJ, int T, int D, int G, int accumulate,
+int pgl_k_i8_crt(const int8_t* R, const double* sA, const double* sB, double* J, long ldj, long strideJ, int D, int G, int nplanes, int accumulate,
                  hipStream_t st) {
     const int Dq = (D + 255) / 256 * 256;
     if (G <= 0) return PGL_OK;
-    CrtArgs c{R, xmax, wmax, J, ldj, strideJ, D, Dq, G, accumulate, pgl_i8_beta(T)};
+    CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes};
     hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 255) / 256, D, G), dim3(256), 0, st, c);
     PGL_CHECK_LAUNCH();
     return PGL_OK;

@@ -6,6 +6,7 @@ the whole shard, then per batch the omega-weighted Gram, posterior assembly, tab
 PyTorch is used for device memory and streams only; all arithmetic is in libpyglm_hip.so (include/pyglm_hip.h).
 """
 import ctypes
+import functools
 
 import numpy as np
 import torch
@@ -19,6 +20,17 @@ I32 = torch.int32
 
 def _r(x, m):
     return (x + m - 1) // m * m
+
+
+def _on_device(fn):
+    """run a GibbsEngine method with the engine's GPU as the current device and put the caller's device back afterwards: the library's
+    launches act on the current HIP device, and an engine must not move its process onto its own device behind the caller's back (a
+    temporary engine on another GPU, several engines in one process)"""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        with torch.cuda.device(self.dev):
+            return fn(self, *args, **kwargs)
+    return wrapped
 
 
 def make_draws(seed, sweep, neuron_ids, N, D):
@@ -81,8 +93,11 @@ class _Dataset(object):
 class GibbsEngine(object):
     OBS = {"bernoulli": 0, "negbin": 1, "gaussian": 2}
 
-    def __init__(self, N, B, n0=0, n1=None, device="cuda:0", obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None,
-                 design_only=False, visit_order=True, gram=None):
+    def __init__(self, N, B, n0=0, n1=None, device=None, obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None,
+                 design_only=False, visit_order=True, gram=None, likelihood_only=False, planes=None):
+        """device: torch device of this shard (default: the process's current GPU).  design_only: only the design matrix is kept (basis
+        convolution).  likelihood_only: activation / log-likelihood / means only -- no sweep buffers, no residue planes (a held-out data
+        set costs X', Y and Psi, nothing else)."""
         if not torch.cuda.is_available():
             raise _lib.PglError("pyglm_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         _lib.load()
@@ -90,8 +105,13 @@ class GibbsEngine(object):
         self.n0, self.n1 = int(n0), int(N if n1 is None else n1)
         self.nloc = self.n1 - self.n0
         assert 0 <= self.n0 < self.n1 <= self.N
-        self.dev = torch.device(device)
-        torch.cuda.set_device(self.dev)
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(self.dev):
+            self._init(N, B, obs, xi, batch, mem_budget_bytes, design_only, visit_order, gram, likelihood_only, planes)
+
+    def _init(self, N, B, obs, xi, batch, mem_budget_bytes, design_only, visit_order, gram, likelihood_only, planes):
         self.obs, self.xi = self.OBS[obs], float(xi)
         self.Dp = _r(self.D + 1, 16)
         self.ldn = _r(self.nloc, 2)
@@ -101,13 +121,16 @@ class GibbsEngine(object):
         if self.R < 1:
             raise ValueError("B=%d too large for the proposal window" % self.B)
         self.datasets = []
-        self.stream = torch.cuda.current_stream(self.dev)
         # the likelihood Gram X'OX: "fp64" = the fp64-MFMA kernel; "int8" = exact integer arithmetic on the int8 MFMA (15 residue planes +
         # CRT, pgl_i8_*; operands rounded to 50-bit fixed point per column -- error at the level of the fp64 product's own); "auto"
         # (default) takes the integer path per data set where it is the faster one and its planes fit in memory (_use_int8)
         import os
         self.gram = gram or os.environ.get("PGL_GRAM", "auto")
         assert self.gram in ("auto", "fp64", "int8")
+        # number of residue planes (moduli) of the integer path: 13 keeps the operand rounding at the fp64 product's own level (column
+        # norms >= 2^49), every further plane buys 4 more bits; None / PGL_I8_PLANES unset = I8_PLANES
+        self.planes = int(planes or os.environ.get("PGL_I8_PLANES", self.I8_PLANES))
+        assert 1 <= self.planes <= _lib.load().pgl_i8_max_planes()
         self._i8_scratch = None
         per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
         if batch is None:
@@ -116,12 +139,18 @@ class GibbsEngine(object):
             batch = max(2, min(self.nloc, budget // per_neuron))
         self.nb = int(min(batch, self.nloc))
         self.design_only = design_only
+        self.likelihood_only = bool(likelihood_only)
         # sweep tableau kept in proposal order (updates after a window touch only the rows not yet proposed); False keeps J's order and
         # full-tableau updates -- same decisions, and the final tableau is then the complete sweep(A, S) (used by a full-size test)
         self.visit_order = bool(visit_order)
-        if not design_only:
+        if likelihood_only:
+            self._alloc_shard()
+        elif not design_only:
             self._alloc_batch()
+            self._alloc_shard()
         self.timings = {}
+        self.keep_logodds = False       # True: sweep() leaves the flip log-odds in self.logodds (parity tests)
+        self.logodds = None
         self.profile = False
         self._ev = []
 
@@ -139,6 +168,7 @@ class GibbsEngine(object):
             h[2].record(torch.cuda.current_stream(self.dev))
             self._ev.append(h)
 
+    @_on_device
     def collect_timings(self):
         """-> {stage: dict(ms=total, calls=n, work=sum)} since the last call"""
         torch.cuda.synchronize(self.dev)
@@ -173,8 +203,10 @@ class GibbsEngine(object):
         self.batch_k = self._z(nb, dtype=I32)
         self.act = self._z(nb, D + 1, dtype=I32)
         self.na = self._z(nb, dtype=I32)
-        # whole-shard state
-        nl = self.nloc
+
+    def _alloc_shard(self):
+        """whole-shard state (all a likelihood-only engine needs besides its data)"""
+        N, D, nl = self.N, self.D, self.nloc
         self.a_dev = self._z(nl, N, dtype=I32)
         self.W_dev = self._z(nl, D)
         self.b_dev = self._z(nl)
@@ -193,6 +225,7 @@ class GibbsEngine(object):
         return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
     # ------------------------------------------------------------------ data
+    @_on_device
     def add_data(self, Y, X=None, basis=None):
         """models.py:66-80: Y is (T, N) counts; X (T, N, B) optional, else built on the device from `basis` (L, B)
         by pgl_design_matrix (utils/basis.py:5-34)."""
@@ -226,16 +259,26 @@ class GibbsEngine(object):
         ds.Y = self._z(T, self.ldn)
         ds.Y[:, :self.nloc] = torch.from_numpy(np.ascontiguousarray(Y[:, self.n0:self.n1])).to(self.dev)
         ds.Psi = self._z(T, self.ldn)
-        ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
+        if not self.likelihood_only:
+            ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
         ds.llpart = self._z(_lib.load().pgl_pg_loglik_partials(T), self.nloc)
+        if self.likelihood_only:
+            torch.cuda.synchronize(self.dev)
+            ds.X = ds.OK = None                   # the activation contraction reads X' only
+            ds.int8 = False
+            return ds
         ds.int8 = self._use_int8(T)
         if ds.int8:
-            # residue planes of X (once per data set) and the column maxima that fix the fixed-point scales
+            # residue planes of X (once per data set), scaled column by column from the columns' norms and maxima
             lib = _lib.load()
-            ds.xmax = self._z(self.D)
-            call("pgl_i8_colmax", ptr(ds.X), self.Dp, T, self.D, ptr(ds.xmax), st)
-            ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T), dtype=torch.int8, device=self.dev)
-            call("pgl_i8_planes", ptr(ds.X), self.Dp, None, 0, ptr(ds.xmax), None, ptr(ds.PA), T, self.D, 1, st)
+            if lib.pgl_i8_norm_bits(self.planes, T) < 8:
+                raise ValueError("%d residue planes cannot hold T = %d time bins" % (self.planes, T))
+            stat = self._z(2, self.D)
+            ds.sA = self._z(self.D)
+            call("pgl_i8_colstats", ptr(ds.X), self.Dp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
+            call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, self.planes, ptr(ds.sA), st)
+            ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * self.planes, dtype=torch.int8, device=self.dev)
+            call("pgl_i8_planes", ptr(ds.X), self.Dp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, self.planes, st)
             self._i8_reserve(T)
             torch.cuda.synchronize(self.dev)
         if self.obs == 2:
@@ -247,17 +290,18 @@ class GibbsEngine(object):
         return ds
 
     # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
-    I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are 15 T D bytes each)
+    I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
+    I8_PLANES = 13        # default number of moduli (see __init__; DESIGN.md section 8c has the measured error levels)
     I8_MIN_D, I8_MIN_T = 1024, 2048
 
     def _i8_need(self, T, G):
         lib = _lib.load()
-        return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D))
+        return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D)) // lib.pgl_i8_max_planes() * self.planes
 
     def _use_int8(self, T):
         """the Gram of a data set goes through the int8 MFMA if asked for, or (auto) if the shape is one where it is faster than the fp64
         kernel (256 x 256 tiles, 15 planes: not for small D or short T) and X's planes plus one neuron's scratch fit beside everything else"""
-        if self.obs == 2 or self.design_only or self.gram == "fp64":
+        if self.obs == 2 or self.design_only or self.likelihood_only or self.gram == "fp64":
             return False
         if self.gram == "int8":
             return True
@@ -278,17 +322,24 @@ class GibbsEngine(object):
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info(self.dev)
         G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // self._i8_need(T, 1))))
-        self._i8_scratch = (self._i8_need(T, G), T, G, torch.empty(G * lib.pgl_i8_plane_bytes(self.D, T), dtype=torch.int8, device=self.dev),
-                            torch.empty(G * lib.pgl_i8_residue_bytes(self.D), dtype=torch.int8, device=self.dev), self._z(self.nb))
+        mp = lib.pgl_i8_max_planes()
+        self._i8_scratch = (self._i8_need(T, G), T, G,
+                            torch.empty(G * lib.pgl_i8_plane_bytes(self.D, T) // mp * self.planes, dtype=torch.int8, device=self.dev),
+                            torch.empty(G * lib.pgl_i8_residue_bytes(self.D) // mp * self.planes, dtype=torch.int8, device=self.dev),
+                            self._z(3, G, self.D))          # per group: column maxima, sums of squares, scales of omega_g X
 
+    @_on_device
     def set_noise(self, eta):
         """noise variances eta (nloc,) of the Gaussian observation model (regression.py:380-398)"""
         assert self.obs == 2
         self.eta = np.asarray(eta, dtype=np.float64).reshape(self.nloc).copy()
         self.inv_eta.copy_(torch.from_numpy(1.0 / self.eta))
 
+    @_on_device
     def design_matrix(self, i=0):
         ds = self.datasets[i]
+        if ds.X is None:                          # likelihood-only engines keep the transposed copy only
+            return ds.Xt[:self.D, :ds.T].t().contiguous().cpu().numpy().reshape(ds.T, self.N, self.B)
         return ds.X[:ds.T, :self.D].cpu().numpy().reshape(ds.T, self.N, self.B)
 
     # ------------------------------------------------------------------ activation / PG / log-likelihood
@@ -319,6 +370,7 @@ class GibbsEngine(object):
             self._toc(h)
         return self.ll
 
+    @_on_device
     def log_likelihood(self, a, W, b):
         """per-neuron sum_t log p(y_t | psi_t) (regression.py:491-494 summed as at models.py:93-94)."""
         self._upload_weights(a, W, b)
@@ -331,12 +383,14 @@ class GibbsEngine(object):
             ll = -0.5 * T * np.log(2 * np.pi * self.eta) - 0.5 * ll / self.eta
         return ll
 
+    @_on_device
     def sse(self, a, W, b):
         """sum_t (y - mean)^2 per local neuron, the statistic of _resample_eta (regression.py:433-445)"""
         assert self.obs == 2
         self._upload_weights(a, W, b)
         return self._psi_pass(False, 0, 0).cpu().numpy().copy()
 
+    @_on_device
     def psi(self, a, W, b, i=0):
         self._upload_weights(a, W, b)
         self._psi_pass(False, 0, 0)
@@ -344,6 +398,7 @@ class GibbsEngine(object):
         return ds.Psi[:, :self.nloc].cpu().numpy()
 
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
+    @_on_device
     def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None):
         """regression.py:265-280 for every local neuron.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in
         natural form (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
@@ -351,6 +406,8 @@ class GibbsEngine(object):
         host_overlap: optional callable run on the host once the first batch's Gram has been queued (seconds of GPU work during
         which the host would only wait), e.g. to draw the next sweep's permutations."""
         nloc, N, B, D, ldn, Dp, ldj = self.nloc, self.N, self.B, self.D, self.ldn, self.Dp, self.ldj
+        if self.likelihood_only or self.design_only:
+            raise _lib.PglError("this engine was built without sweep buffers (likelihood_only / design_only)")
         st = self._st()
         a = np.asarray(a).astype(bool).copy()
         rho = np.asarray(rho, dtype=np.float64)
@@ -363,12 +420,16 @@ class GibbsEngine(object):
                 ds.OK[:ds.T, :nloc] = torch.from_numpy(np.ascontiguousarray(om, dtype=np.float64)).to(self.dev)
         # border sums  [Omega|Kappa]' [X, 1]   (regression.py:253-260)
         for i, ds in enumerate(self.datasets):
+            h = self._tic("border", 4.0 * ds.T * (D + 1) * nloc)
             call("pgl_contract_tn", ptr(ds.OK), 2 * ldn, 2 * ldn, ptr(ds.X), Dp, Dp, ptr(self.border), Dp, 2 * ldn, D + 1, ds.Tp,
                  1.0, 1.0 if i > 0 else 0.0, st)
+            self._toc(h)
         a[det] = np.round(rho[det]).astype(bool)                         # regression.py:274-275
         a_i32 = torch.from_numpy(a.astype(np.int32)).to(self.dev)
         self.a_dev.copy_(a_i32)
         self.status.zero_()
+        # test hook: the log-odds of every proposal step, (nloc, N) in proposal order, NaN where no proposal was made
+        self.logodds = torch.full((nloc, N), float("nan"), dtype=F64, device=self.dev) if self.keep_logodds else None
         label = None
         if isinstance(Jw, BlockPrior):
             label, c0, hw, Jw = Jw.label, Jw.c0_u[Jw.label], Jw.hw_u, Jw.Jw_u
@@ -419,26 +480,36 @@ class GibbsEngine(object):
             self._toc(h)
 
     def _gram_int8(self, i, ds, s, nbb, J):
-        """the same Gram through pgl_i8_* in groups of G neurons (the 15 residue planes of omega_n X are 15 T D bytes per neuron)"""
+        """the same Gram through pgl_i8_* in groups of G neurons (the residue planes of omega_n X are `planes` T D bytes per neuron)"""
         D, ldn, Dp, ldj = self.D, self.ldn, self.Dp, self.ldj
         st = self._st()
-        _, _, G, PB, R, wmax = self._i8_scratch
-        om = ctypes.c_void_p(ds.OK.data_ptr() + 8 * s)
-        wmax.zero_()
-        call("pgl_i8_colmax", om, 2 * ldn, ds.T, nbb, ptr(wmax), st)
+        G = self._i8_scratch[2]
         for g0 in range(0, nbb, G):
             gz = min(G, nbb - g0)
-            h = self._tic("gram.planes", 8.0 * gz * ds.T * D)
-            call("pgl_i8_planes", ptr(ds.X), Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * (s + g0)), 2 * ldn, ptr(ds.xmax),
-                 ctypes.c_void_p(wmax.data_ptr() + 8 * g0), ptr(PB), ds.T, D, gz, st)
-            self._toc(h)
-            h = self._tic("gram.int8", float(gz) * ds.T * D * (D + 1))
-            call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, st)
-            self._toc(h)
-            h = self._tic("gram.crt", 15.0 * gz * D * (D + 1) / 2)
-            call("pgl_i8_crt", ptr(R), ptr(ds.xmax), ctypes.c_void_p(wmax.data_ptr() + 8 * g0),
-                 ctypes.c_void_p(J.data_ptr() + 8 * g0 * ldj * ldj), ldj, ldj * ldj, ds.T, D, gz, int(i > 0), st)
-            self._toc(h)
+            self._i8_group(ds, ctypes.c_void_p(ds.OK.data_ptr() + 8 * (s + g0)), 2 * self.ldn, gz,
+                           ctypes.c_void_p(J.data_ptr() + 8 * g0 * self.ldj * self.ldj), int(i > 0))
+
+    def _i8_group(self, ds, om, ldo, gz, Jp, accumulate):
+        """J[g] (+)= X' diag(om[:, g]) X for gz <= group size weight columns at `om` (device pointer, leading dimension ldo): column
+        statistics -> scales -> residue planes -> int8 products mod p -> CRT"""
+        D, Dp, ldj = self.D, self.Dp, self.ldj
+        st = self._st()
+        _, _, G, PB, R, stat = self._i8_scratch
+        assert gz <= G
+        npl = self.planes
+        h = self._tic("gram.stats", 8.0 * ds.T * D)
+        call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
+        call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
+        self._toc(h)
+        h = self._tic("gram.planes", float(npl) * gz * ds.T * D)        # bytes stored
+        call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
+        self._toc(h)
+        h = self._tic("gram.int8", float(gz) * ds.T * D * (D + 1))
+        call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)
+        self._toc(h)
+        h = self._tic("gram.crt", float(npl) * gz * D * (D + 1) / 2)
+        call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), Jp, ldj, ldj * ldj, ds.T, D, gz, npl, accumulate, st)
+        self._toc(h)
 
     def _post(self, s, nbb, slot, a_host, det, dev, skip):
         """posterior assembly, collapsed flips and weight draw of local neurons [s, s+nbb) from J slot `slot`"""
@@ -462,7 +533,8 @@ class GibbsEngine(object):
             vo = int(self.visit_order)
             fs = FlipState(ptr(self.Mtab), ldj, strideJ, nbb, N, B, off4(dev["perm"], s * N), off8(dev["u"], s * N), off8(dev["rho"], s * N),
                            off8(dev["c0"], s * N), off4(self.a_dev, s * N), off4(skip, s), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt),
-                           ptr(self.batch_k), ptr(self.G), ptr(self.Lws), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s), vo)
+                           ptr(self.batch_k), ptr(self.G), ptr(self.Lws), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s), vo,
+                           off8(self.logodds, s * N) if self.logodds is not None else None)
             if vo:
                 call("pgl_flip_visit_order", ctypes.byref(fs), ptr(self.Jbuf), ldj, strideJ, st)
             else:
@@ -512,6 +584,7 @@ class GibbsEngine(object):
         self._toc(hc_)
 
     # test hooks --------------------------------------------------------------------------------------------------
+    @_on_device
     def posterior(self, i):
         """assembled (J_post (D+1,D+1), h_post (D+1,)) of batch slot i as dense symmetric host arrays"""
         D = self.D

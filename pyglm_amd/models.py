@@ -64,10 +64,18 @@ class NonlinearAutoregressiveModel(object):
             import torch
             t = torch.tensor([self.seed], dtype=torch.int64)
             if dist.get_backend() == "nccl":
-                t = t.cuda()
+                t = t.to(self._comm_dev())
             dist.broadcast(t, 0)
             self.seed = int(t.item())
         self.sweeps_done = 0
+        self.comm_seconds = 0.0        # wall time this rank has spent inside collectives (all_gather of rows, scalar all_reduce)
+
+    def _comm_dev(self):
+        """device the RCCL collectives of this rank stage through: the shard's GPU"""
+        import torch
+        if self._engine is not None and hasattr(self._engine, "dev"):
+            return self._engine.dev
+        return torch.device(self._device) if self._device else torch.device("cuda", torch.cuda.current_device())
 
     # ---- engine
     @property
@@ -121,7 +129,9 @@ class NonlinearAutoregressiveModel(object):
         dist = _dist()
         if dist is None:
             return arr
+        import time
         import torch
+        t0 = time.perf_counter()
         nccl = dist.get_backend() == "nccl"
         counts = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
         maxc = max(hi - lo for lo, hi in counts)
@@ -129,10 +139,12 @@ class NonlinearAutoregressiveModel(object):
         pad[:arr.shape[0]] = arr
         t = torch.from_numpy(np.ascontiguousarray(pad))
         if nccl:
-            t = t.cuda()
+            t = t.to(self._comm_dev())
         outs = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(outs, t)
-        return np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(outs, counts)], axis=0)
+        out = np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(outs, counts)], axis=0)
+        self.comm_seconds += time.perf_counter() - t0
+        return out
 
     def log_likelihood(self, datas=None):
         """(models.py:82-96) sum over datasets and neurons; `datas` other than the stored data is evaluated through a
@@ -140,27 +152,48 @@ class NonlinearAutoregressiveModel(object):
         if datas is None:
             eng = self.engine
         else:
-            from .engine import GibbsEngine
-            eng = (self._engine_factory or GibbsEngine)(self.N, self.B, self.n0, self.n1, obs=self.engine_obs(),
-                                                               xi=getattr(self.regressions[0], "xi", 1.0))
-            for d in datas:
-                if isinstance(d, tuple):
-                    eng.add_data(d[1], X=d[0] if not isinstance(d[0], _LazyX) else None, basis=self.basis)
-                else:
-                    eng.add_data(d, basis=self.basis)
+            eng = self._heldout_engine(datas)
         a, W, b = self._local_state()
         if self.engine_obs() == "gaussian":
             eng.set_noise([r.eta for r in self.regressions[self.n0:self.n1]])
         ll = float(np.sum(eng.log_likelihood(a, W, b)))
         dist = _dist()
         if dist is not None:
+            import time
             import torch
+            t0 = time.perf_counter()
             t = torch.tensor([ll], dtype=torch.float64)
             if dist.get_backend() == "nccl":
-                t = t.cuda()
+                t = t.to(self._comm_dev())
             dist.all_reduce(t)            # the only collective on the likelihood path: one fp64 scalar
             ll = float(t.item())
+            self.comm_seconds += time.perf_counter() - t0
         return ll
+
+    def _heldout_engine(self, datas):
+        """likelihood-only engine (X', Y, Psi: no sweep buffers, no residue planes) for data other than the stored data, on THIS shard's
+        device; cached by content, so evaluating the same held-out set every iteration uploads it once"""
+        from .utils.utils import fingerprint
+        from .engine import GibbsEngine
+        items = []
+        for d in datas:
+            X, Y = d if isinstance(d, tuple) else (None, d)
+            if isinstance(X, _LazyX):
+                X = None
+            items.append((X, np.asarray(Y)))
+        key = tuple((None if X is None else fingerprint(X), fingerprint(Y)) for X, Y in items)
+        cache = getattr(self, "_heldout_cache", None)
+        if cache is None or cache[0] != key:
+            self._heldout_cache = None
+            kw = dict(obs=self.engine_obs() or "bernoulli", xi=getattr(self.regressions[0], "xi", 1.0), likelihood_only=True)
+            if self._engine_factory is not None:
+                eng = self._engine_factory(self.N, self.B, self.n0, self.n1, **kw)
+            else:
+                eng = GibbsEngine(self.N, self.B, self.n0, self.n1, device=self.engine.dev, **kw)
+            for X, Y in items:
+                eng.add_data(Y, X=X, basis=self.basis)
+            cache = self._heldout_cache = (key, eng)
+        return cache[1]
 
     def engine_obs(self):
         return getattr(self.regressions[0], "_obs", "bernoulli")
@@ -214,11 +247,12 @@ class NonlinearAutoregressiveModel(object):
         if cache is not None and cache[0] == versions:
             rho, Jw, hw, Jb, hb, c0 = cache[1]          # pushed by resample_network and untouched since
         else:
-            rho = np.array([r.rho for r in regs])
-            S_w = np.array([r.S_w for r in regs])
-            mu_w = np.array([r.mu_w for r in regs])
-            S_b = np.array([r.S_b[0, 0] for r in regs])
-            mu_b = np.array([r.mu_b[0] for r in regs])
+            hyp = [r._hyper() for r in regs]            # internal read: does not mark the terms stale (the public properties do)
+            rho = np.array([h[0] for h in hyp])
+            S_w = np.array([h[1] for h in hyp])
+            mu_w = np.array([h[2] for h in hyp])
+            S_b = np.array([h[3][0, 0] for h in hyp])
+            mu_b = np.array([h[4][0] for h in hyp])
             Jw, hw, Jb, hb, c0 = prior_terms(S_w, mu_w, S_b, mu_b)
             self._hyper_cache = (versions, (rho, Jw, hw, Jb, hb, c0))
         # the non-PG random inputs depend on (seed, sweep, neuron) only: those of the NEXT sweep are drawn while the GPU works on
@@ -258,6 +292,35 @@ class NonlinearAutoregressiveModel(object):
             r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
             if gaussian:
                 r.eta = float(eta_all[n])
+
+    # ---- chain state (checkpoint / resume; also lets two samplers be run from one state)
+    _STATE_ATTRS = ("regressions", "sweeps_done", "_hyper_cache", "network")
+
+    def get_state(self):
+        """deep copy of everything a sweep reads or writes on the host: the regressions (a, W, b, hyper-parameters, noise variances), the
+        network prior, the sweep counter (the random inputs are keyed by (seed, sweep, neuron)) and the cached natural-parameter terms.
+        Device buffers hold no chain state between sweeps.  `set_state(get_state())` resumes the chain exactly."""
+        import copy
+        keep = {}
+        for r in self.regressions:               # stand-alone engines hold device memory and are not chain state
+            keep[id(r)] = (r.__dict__.pop("_engine_cache", None), r.__dict__.pop("_lik_engine_cache", None))
+        try:
+            st = {k: copy.deepcopy(getattr(self, k)) for k in self._STATE_ATTRS if hasattr(self, k)}
+        finally:
+            for r in self.regressions:
+                r._engine_cache, r._lik_engine_cache = keep[id(r)]
+        st["seed"] = self.seed
+        return st
+
+    def set_state(self, state):
+        import copy
+        assert state["seed"] == self.seed, "state of a chain with another seed"
+        for k in self._STATE_ATTRS:
+            if k in state:
+                setattr(self, k, copy.deepcopy(state[k]))
+        for r in self.regressions:
+            r._engine_cache = r._lik_engine_cache = None
+        self._draws_ahead = None
 
     def plot(self, *args, **kwargs):
         raise NotImplementedError("plotting is outside the scope of the MI355X hot path (SURVEY.md section 2, row 8)")
@@ -330,8 +393,8 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
             label[np.arange(nl), np.arange(n0, n1)] = 1
         Jw_u, hw_u, _, _, c0_u = prior_terms(np.array(S_u)[None], np.array(mu_u)[None], np.ones(1), np.zeros(1))
         prior = BlockPrior(Jw_u[0], hw_u[0], c0_u[0], label)
-        S_b = np.array([r.S_b[0, 0] for r in regs])
-        mu_b = np.array([r.mu_b[0] for r in regs])
+        S_b = np.array([r._S_b[0, 0] for r in regs])
+        mu_b = np.array([r._mu_b[0] for r in regs])
         Jb = 1.0 / S_b
         self._hyper_cache = (tuple(r._hyp_version for r in regs), (np.array(rho[n0:n1], dtype=float), prior, None, Jb, Jb * mu_b, None))
 
@@ -369,8 +432,8 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
         nl = n1 - n0
         from .engine import BlockPrior
         prior = BlockPrior(Jw_u[0], hw_u[0], c0_u[0], idx.reshape(nl, N))      # tables + labels: never expanded to (nl, N, B, B)
-        S_b = np.array([r.S_b[0, 0] for r in regs])
-        mu_b = np.array([r.mu_b[0] for r in regs])
+        S_b = np.array([r._S_b[0, 0] for r in regs])
+        mu_b = np.array([r._mu_b[0] for r in regs])
         Jb = 1.0 / S_b
         self._hyper_cache = (tuple(r._hyp_version for r in regs), (np.array(rho[n0:n1], dtype=float), prior, None, Jb, Jb * mu_b, None))
 

@@ -6,10 +6,37 @@ O(N^3 B^2) per-row rebuilds (networks.py:96-130 are re-evaluated N times at mode
 `pybasicbayes.distributions.Gaussian` (NIW) is not vendored with the reference; `_NIW` restates its published conjugate
 update and draw (PARITY UNPINNED against the third-party package, see oracle/pyglm_oracle.py).
 """
+import warnings
+
 import numpy as np
 import scipy.linalg as sla
 
 from .utils.utils import expand_scalar, expand_cov
+
+# True (default): the network classes are constructed exactly as the reference constructs them, including three accidents of its code
+# that decide the results a `network_kwargs` user gets (pinned by fixture G12, captured from the reference's own constructors):
+#   * the mixins chain through `super().__init__(N, B)` (networks.py:83, 180, 196), so of all keyword arguments only `rho` / `rho_self`
+#     (sparse networks) ever arrive: the NIW hyper-parameters are always the defaults mu_0 = 0, sigma_0 = I, kappa_0 = 1, nu_0 = 3, and a
+#     FixedMean network always has mu = 0;
+#   * the self-connection Gaussian gets nu_0 raw (networks.py:94) where the shared one gets max(nu_0, B + 2) (:89);
+#   * `_FixedWeightsMixin` builds its covariance from `mu` (networks.py:159), i.e. Sigma = 0.
+# Where that leaves the reference unable to run at all (nu_0 = 3 < B: pybasicbayes' inverse-Wishart draw fails for B > 3; Sigma = 0: the
+# regressions cannot invert it) the first is floored at B + 2 with a warning and the second raises like the reference does.
+# False: keyword arguments reach the mixin they are meant for, both Gaussians get max(nu_0, B + 2), Sigma comes from `sigma`.
+REFERENCE_QUIRKS = True
+
+
+def set_reference_quirks(on):
+    """switch the constructor behaviour described above (module-wide; affects networks constructed afterwards)"""
+    global REFERENCE_QUIRKS
+    REFERENCE_QUIRKS = bool(on)
+
+
+def _dropped(cls, kw, keep=()):
+    lost = sorted(k for k in kw if k not in keep)
+    if lost:
+        warnings.warn("%s: keyword argument(s) %s never reach their mixin in the reference (pyglm/networks.py:83, 180, 196) and are ignored "
+                      "here too; pyglm_amd.networks.set_reference_quirks(False) makes them take effect" % (cls, ", ".join(lost)), stacklevel=3)
 
 
 def _sample_invwishart(S, nu, rng):
@@ -31,7 +58,7 @@ class _NIW(object):
     def __init__(self, mu_0, sigma_0, kappa_0, nu_0, rng=None):
         self.mu_0, self.sigma_0 = np.asarray(mu_0, float), np.asarray(sigma_0, float)
         self.kappa_0, self.nu_0 = float(kappa_0), float(nu_0)
-        self.rng = np.random if rng is None else rng
+        self.rng = rng                     # None = NumPy's global generator (looked up at use: a module cannot be deep-copied)
         self.resample()
 
     def resample(self, data=()):
@@ -46,8 +73,9 @@ class _NIW(object):
             mu_n = (self.kappa_0 * self.mu_0 + n * xbar) / (self.kappa_0 + n)
             sigma_n = self.sigma_0 + centred.T.dot(centred) + self.kappa_0 * n / (self.kappa_0 + n) * np.outer(dev, dev)
             kappa_n, nu_n = self.kappa_0 + n, self.nu_0 + n
-        self.sigma = _sample_invwishart(sigma_n, nu_n, self.rng)
-        self.mu = self.rng.multivariate_normal(mu_n, self.sigma / kappa_n)
+        rng = np.random if self.rng is None else self.rng
+        self.sigma = _sample_invwishart(sigma_n, nu_n, rng)
+        self.mu = rng.multivariate_normal(mu_n, self.sigma / kappa_n)
 
 
 class _NetworkModel(object):
@@ -78,8 +106,16 @@ class _IndependentGaussianMixin(_NetworkModel):
         self._gaussian = _NIW(mu_0, sigma_0, kappa_0, max(nu_0, B + 2.))
         self.is_diagonal_weight_special = is_diagonal_weight_special
         if is_diagonal_weight_special:
-            # reference networks.py:94 passes the raw nu_0 (= 3), an improper inverse-Wishart for B > 3; floor it as :89 does
-            self._self_gaussian = _NIW(mu_0, sigma_0, kappa_0, max(nu_0, B + 2.))
+            nu_self = max(nu_0, B + 2.)
+            if REFERENCE_QUIRKS:
+                # networks.py:94 passes nu_0 raw.  With nu_0 < B the reference cannot even be constructed (the inverse-Wishart draw of the
+                # third-party Gaussian needs nu >= B), so that case keeps the floor of :89
+                if nu_0 >= B:
+                    nu_self = nu_0
+                else:
+                    warnings.warn("self-connection prior: nu_0 = %g < B = %d; the reference fails to construct this network (networks.py:94), "
+                                  "nu_0 is floored at B + 2 as at networks.py:89" % (nu_0, B), stacklevel=3)
+            self._self_gaussian = _NIW(mu_0, sigma_0, kappa_0, nu_self)
 
     def _rows(self, off, diag, n0, n1):
         out = np.empty((n1 - n0, self.N) + off.shape)
@@ -126,7 +162,7 @@ class _FixedWeightsMixin(_NetworkModel):
     def __init__(self, N, B, mu=0.0, sigma=1.0, mu_self=None, sigma_self=None, **kwargs):
         _NetworkModel.__init__(self, N, B)
         self._mu = expand_scalar(mu, (N, N, B))
-        self._sigma = expand_cov(sigma, (N, N, B, B))
+        self._sigma = expand_cov(mu if REFERENCE_QUIRKS else sigma, (N, N, B, B))       # networks.py:159 builds Sigma from `mu`
         if (mu_self is not None) and (sigma_self is not None):
             r = np.arange(N)
             self._mu[r, r, :] = expand_scalar(mu_self, (N, B))
@@ -164,28 +200,45 @@ class _DenseAdjacencyMixin(_NetworkModel):
     rho = property(lambda self: self._rho)
 
 
+def _split(kw):
+    return {k: v for k, v in kw.items() if k not in ("rho", "rho_self")}, {k: v for k, v in kw.items() if k in ("rho", "rho_self")}
+
+
 class FixedMeanDenseNetwork(_DenseAdjacencyMixin, _FixedWeightsMixin):
     def __init__(self, N, B, **kw):
+        if REFERENCE_QUIRKS:
+            _dropped("FixedMeanDenseNetwork", kw)
+            kw = {}
         _FixedWeightsMixin.__init__(self, N, B, **kw)
-        _DenseAdjacencyMixin.__init__(self, N, B, **kw)
+        _DenseAdjacencyMixin.__init__(self, N, B)
 
 
 class FixedMeanSparseNetwork(_FixedAdjacencyMixin, _FixedWeightsMixin):
     def __init__(self, N, B, **kw):
-        _FixedWeightsMixin.__init__(self, N, B, **kw)
-        _FixedAdjacencyMixin.__init__(self, N, B, **{k: v for k, v in kw.items() if k in ("rho", "rho_self")})
+        wkw, akw = _split(kw)
+        if REFERENCE_QUIRKS:
+            _dropped("FixedMeanSparseNetwork", wkw)
+            wkw = {}
+        _FixedWeightsMixin.__init__(self, N, B, **wkw)
+        _FixedAdjacencyMixin.__init__(self, N, B, **akw)
 
 
 class NIWDenseNetwork(_DenseAdjacencyMixin, _IndependentGaussianMixin):
     def __init__(self, N, B, **kw):
+        if REFERENCE_QUIRKS:
+            _dropped("NIWDenseNetwork", kw)
+            kw = {}
         _IndependentGaussianMixin.__init__(self, N, B, **kw)
         _DenseAdjacencyMixin.__init__(self, N, B)
 
 
 class NIWSparseNetwork(_FixedAdjacencyMixin, _IndependentGaussianMixin):
-    """NB: in the reference the MRO drops **kwargs at networks.py:180 (every NIWSparseNetwork gets the default NIW
-    hyper-parameters and rho = 0.5 unless rho/rho_self are given); here the keyword arguments reach both mixins."""
+    """(networks.py:283-285; see REFERENCE_QUIRKS for which keyword arguments arrive)"""
 
     def __init__(self, N, B, **kw):
-        _IndependentGaussianMixin.__init__(self, N, B, **{k: v for k, v in kw.items() if k not in ("rho", "rho_self")})
-        _FixedAdjacencyMixin.__init__(self, N, B, **{k: v for k, v in kw.items() if k in ("rho", "rho_self")})
+        wkw, akw = _split(kw)
+        if REFERENCE_QUIRKS:
+            _dropped("NIWSparseNetwork", wkw)
+            wkw = {}
+        _IndependentGaussianMixin.__init__(self, N, B, **wkw)
+        _FixedAdjacencyMixin.__init__(self, N, B, **akw)

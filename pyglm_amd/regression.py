@@ -8,7 +8,7 @@ stand-alone regression (examples/bernoulli_regression.py style) builds a one-neu
 import numpy as np
 import numpy.random as npr
 
-from .utils.utils import logistic, expand_scalar, expand_cov
+from .utils.utils import logistic, expand_scalar, expand_cov, fingerprint
 
 
 class _BlockRows(object):
@@ -43,9 +43,12 @@ class _SparseScalarRegressionBase(object):
             self.W = self.a[:, None] * (self.mu_w + np.einsum("nij,nj->ni", L, npr.randn(N, B)))
         self.b = npr.multivariate_normal(self.mu_b, self.S_b)
         self._engine_cache = None
+        self._lik_engine_cache = None
 
-    # hyper-parameter setters broadcast scalars (:95-136); every assignment bumps a version so that the population model
-    # can tell whether the natural-parameter terms it cached are still current
+    # hyper-parameter setters broadcast scalars (:95-136).  The population model caches the natural-parameter terms of its regressions;
+    # a version counter says whether they are still current.  It is bumped by every assignment AND by every read through the public
+    # properties: a getter hands out the live array, and the reference's users edit those in place (`reg.rho[m] = 0.9`) -- after such a
+    # read the terms are recomputed from the arrays, as the reference does every sweep (:266).  Internal code reads `_hyper()`.
     _hyp_version = 0
 
     def _set(self, name, value):
@@ -59,10 +62,18 @@ class _SparseScalarRegressionBase(object):
             setattr(self, name, v)
         return v
 
-    rho = property(lambda self: self._rho, lambda self, v: self._set("_rho", expand_scalar(v, (self.N,))))
-    mu_w = property(lambda self: self._get_rows("_mu_w"), lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B))))
-    mu_b = property(lambda self: self._mu_b, lambda self, v: self._set("_mu_b", expand_scalar(v, (1,))))
-    S_w = property(lambda self: self._get_rows("_S_w"), lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B))))
+    def _touch(self, name, rows=False):
+        self._hyp_version = self._hyp_version + 1
+        return self._get_rows(name) if rows else getattr(self, name)
+
+    def _hyper(self):
+        """(rho, S_w, mu_w, S_b, mu_b) without marking the cached terms stale"""
+        return self._rho, self._get_rows("_S_w"), self._get_rows("_mu_w"), self._S_b, self._mu_b
+
+    rho = property(lambda self: self._touch("_rho"), lambda self, v: self._set("_rho", expand_scalar(v, (self.N,))))
+    mu_w = property(lambda self: self._touch("_mu_w", True), lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B))))
+    mu_b = property(lambda self: self._touch("_mu_b"), lambda self, v: self._set("_mu_b", expand_scalar(v, (1,))))
+    S_w = property(lambda self: self._touch("_S_w", True), lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B))))
 
     def _push_block_prior(self, mu_off, S_off, mu_self, S_self, n, rho_row):
         """the hyper-parameter push of models.py:233-236 for a prior with one shared weight block and (optionally) one for the
@@ -73,7 +84,7 @@ class _SparseScalarRegressionBase(object):
 
     @property
     def S_b(self):
-        return self._S_b
+        return self._touch("_S_b")
 
     @S_b.setter
     def S_b(self, value):
@@ -109,23 +120,31 @@ class _SparseScalarRegressionBase(object):
         return self._flatten_X(X), y
 
     # ---- GPU-backed stand-alone operations
-    def _engine(self, datas):
+    def _engine(self, datas, likelihood_only=False):
+        """one-neuron engine holding `datas` = [(X, y), ...] on the GPU.  Cached by CONTENT (utils.fingerprint of every array): a second
+        call with equal data reuses the device copy; different data of the same shape, or data edited in place, is uploaded again.
+        Activation / mean / log-likelihood calls use a likelihood-only engine keyed by X alone (no sweep buffers, y irrelevant)."""
         from .engine import GibbsEngine
-        key = tuple((id(X), id(y), X.shape[0]) for X, y in datas)
-        if self._engine_cache is None or self._engine_cache[0] != key:
-            eng = GibbsEngine(self.N, self.B, 0, 1, obs=self._obs, xi=getattr(self, "xi", 1.0), batch=1)
-            for X, y in datas:
-                X, y = self.extract_data((X, y))
+        flat = [self.extract_data((X, y)) for X, y in datas]
+        key = (bool(likelihood_only),) + tuple((fingerprint(X), None if likelihood_only else fingerprint(y)) for X, y in flat)
+        slot = "_lik_engine_cache" if likelihood_only else "_engine_cache"
+        cache = getattr(self, slot, None)
+        if cache is None or cache[0] != key:
+            setattr(self, slot, None)              # release the previous engine's device memory before allocating the next
+            eng = GibbsEngine(self.N, self.B, 0, 1, obs=self._obs, xi=getattr(self, "xi", 1.0), batch=1, likelihood_only=likelihood_only)
+            for X, y in flat:
                 Y = np.zeros((X.shape[0], self.N))
-                Y[:, 0] = np.asarray(y, dtype=float).ravel()
-                eng.add_data(Y, X=X.reshape(-1, self.N, self.B))
-            self._engine_cache = (key, eng)
-        return self._engine_cache[1]
+                if not likelihood_only:
+                    Y[:, 0] = np.asarray(y, dtype=float).ravel()
+                eng.add_data(Y, X=np.asarray(X, dtype=float).reshape(-1, self.N, self.B))
+            cache = (key, eng)
+            setattr(self, slot, cache)
+        return cache[1]
 
     def activation(self, X):
         """psi = X.vec(a*W) + b  (:195-201)"""
         X = self._flatten_X(X)
-        eng = self._engine([(X, np.zeros(X.shape[0]))])
+        eng = self._engine([(X, np.zeros(X.shape[0]))], likelihood_only=True)
         return eng.psi(self.a[None], self.W[None], self.b)[:, 0]
 
     def _before_sweep(self, eng):

@@ -44,7 +44,7 @@ def interpolate_basis(basis, dt, dt_max, norm=True, allow_instantaneous=False):
     return out
 
 
-def convolve_with_basis(S, basis, device="cuda:0"):
+def convolve_with_basis(S, basis, device=None):
     """(T,N) counts -> (T,N,B) causally filtered regressors (basis.py:5-34), computed by pgl_design_matrix on the GPU."""
     from ..engine import GibbsEngine
     S = np.asarray(S, dtype=float)

@@ -302,6 +302,19 @@ def main():
     out["M_net_offdiag_data"] = glm.network._gaussian.last_data
     out["M_net_diag_data"] = glm.network._self_gaussian.last_data
 
+    # G12: what the reference's network constructors do with their keyword arguments (networks.py:83-94 the NIW hyper-parameters of the
+    # two Gaussians, :178-183 / :271-285 the mixin order that decides which keywords arrive at all).  The Gaussian stand-in records the
+    # hyper-parameters it was constructed with; captured for B on both sides of the nu_0 >= B boundary.
+    from pyglm.networks import NIWSparseNetwork, NIWDenseNetwork, FixedMeanSparseNetwork
+    for name, cls in (("sparse", NIWSparseNetwork), ("dense", NIWDenseNetwork)):
+        for B_ in (1, 2, 3, 5):
+            net = cls(3, B_, nu_0=7.0, kappa_0=3.0, mu_0=0.5, sigma_0=2.0, rho=0.2, rho_self=0.9)
+            g_, s_ = net._gaussian, net._self_gaussian
+            out["N_%s_B%d_niw" % (name, B_)] = np.array([g_.nu_0, g_.kappa_0, g_.mu_0[0], g_.sigma_0[0, 0], s_.nu_0, s_.kappa_0, s_.mu_0[0], s_.sigma_0[0, 0]])
+            out["N_%s_B%d_rho" % (name, B_)] = np.array(net.rho)
+    net = FixedMeanSparseNetwork(3, 2, mu=0.7, sigma=4.0, rho=0.3)
+    out["N_fixed_mu"], out["N_fixed_sigma"], out["N_fixed_rho"] = np.array(net.mu_W), np.array(net.sigma_W), np.array(net.rho)
+
     path = os.path.join(OUT, "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%d arrays, %.1f KB" % (len(out), os.path.getsize(path) / 1024))

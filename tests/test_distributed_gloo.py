@@ -43,8 +43,14 @@ def _run_model(world, rank, port, out_path, kind="bernoulli"):
         model.resample_model()
         lls.append(model.log_likelihood())
     means = model.means[0]
+    # held-out data goes through a second (likelihood-only) engine on the same shard; raw spikes, (X, Y) tuples, and a repeat (cache hit)
+    Y2 = (np.random.RandomState(5).rand(150, N) < 0.2).astype(float)
+    if kind == "gaussian":
+        Y2 = Y2 + np.random.RandomState(6).randn(150, N)
+    held = [model.log_likelihood([Y2]), model.log_likelihood([(model._heldout_engine([Y2]).design_matrix(0), Y2)]),
+            model.log_likelihood([Y2, Y[:100]]), model.log_likelihood([Y2])]
     if rank == 0:
-        np.savez(out_path, A=model.adjacency, W=model.weights, b=model.biases, lls=np.array(lls), means=means,
+        np.savez(out_path, held=np.array(held), A=model.adjacency, W=model.weights, b=model.biases, lls=np.array(lls), means=means,
                  rho=np.array([r.rho for r in model.regressions]), S_w=np.array([r.S_w for r in model.regressions]),
                  eta=np.array([getattr(r, "eta", 0.0) for r in model.regressions]))
     if world > 1:
@@ -67,6 +73,7 @@ def test_two_ranks_equal_one(tmp_path):
     for k in a.files:
         np.testing.assert_allclose(a[k], b[k], rtol=1e-12, atol=1e-12, err_msg=k)
     assert a["A"].shape == (5, 5) and a["W"].shape == (5, 5, 2) and a["means"].shape == (400, 5)
+    assert np.isclose(a["held"][0], a["held"][1], rtol=1e-12) and a["held"][0] == a["held"][3] and a["held"][2] < a["held"][0]
     assert np.all(np.isfinite(a["lls"]))
 
 

@@ -54,15 +54,9 @@ def test_gram_identities_at_cfg3_shape():
     blk = J[3, 1280:1408, 1280:1408]                                                             # a diagonal tile is written in full
     assert (blk - blk.t()).abs().max().item() <= 1e-12 * blk.abs().max().item()
     # the same four Grams through the integer matrix cores (what gram='auto' runs at this shape): residue planes, int8 GEMM mod p, CRT
-    assert ds.int8 and eng._i8_scratch is not None
-    _, _, G8, PB, R, wmax = eng._i8_scratch
-    assert G8 >= 4
-    wmax.zero_()
-    call("pgl_i8_colmax", ptr(W), 4, T, 4, ptr(wmax), None)
-    call("pgl_i8_planes", ptr(ds.X), Dp, ptr(W), 4, ptr(ds.xmax), ptr(wmax), ptr(PB), T, D, 4, None)
-    call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), T, D, 4, None)
+    assert ds.int8 and eng._i8_scratch is not None and eng._i8_scratch[2] >= 4
     J8 = torch.zeros(4, ldj, ldj, dtype=torch.float64, device="cuda")
-    call("pgl_i8_crt", ptr(R), ptr(ds.xmax), ptr(wmax), ptr(J8), ldj, ldj * ldj, T, D, 4, 0, None)
+    eng._i8_group(ds, ptr(W), 4, 4, ptr(J8), 0)
     torch.cuda.synchronize()
     L8 = [torch.tril(J8[k, :D, :D]) for k in range(4)]
     for k in range(4):
@@ -200,3 +194,88 @@ def test_cfg5_shape_sweep_with_flips():
     del eng
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def _fullsize_sweep_checks(obs, N, B, T, nloc, rho, S_w, xi=1.0, seed=11):
+    """one sweep of an nloc-neuron shard at a BASELINE.json configuration's own size, from the same state with the likelihood Gram on the
+    integer matrix cores and on the fp64 kernel: identical decisions, weights equal to 1e-8; on the fp64 engine (plain tableau order) the
+    weight draw against an independent torch fp64 Cholesky solve ((x - mu)' J_SS (x - mu) = z'z), J_SS mu = h_S with z = 0, and the
+    final sweep tableau against its definition (M_SS = -J_SS^-1 on a probe vector)."""
+    import gc
+    import torch
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    gc.collect()
+    torch.cuda.empty_cache()
+    basis, Y, rng = _problem(N, B, T)
+    if obs == "negbin":
+        Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)
+    D = N * B
+    a = rng.random((nloc, N)) < 0.8                     # ~4100 initial active rows at cfg3: the chunked initial sweep of the tableau
+    if rho == 1.0:
+        a[:] = True
+    W = rng.standard_normal((nloc, N, B)) * 0.05 * a[:, :, None]
+    b = np.full(nloc, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * S_w, (nloc, N, 1, 1)), np.zeros((nloc, N, B)), np.ones(nloc), np.full(nloc, -2.0))
+    perm, u, z = make_draws(seed, 0, range(nloc), N, D)
+    rho_a = np.full((nloc, N), rho)
+    outs = {}
+    for gram in ("int8", "fp64"):
+        eng = GibbsEngine(N, B, 0, nloc, batch=nloc, obs=obs, xi=xi, gram=gram, visit_order=(gram == "int8"))
+        ds = eng.add_data(Y, basis=basis)
+        assert ds.int8 == (gram == "int8")
+        outs[gram] = eng.sweep(a, W, b, rho_a, *hyp, perm, u, z, seed=seed, sweep=0)
+        if gram == "int8":
+            del eng, ds
+            gc.collect()
+            torch.cuda.empty_cache()
+    a8, W8, b8, ll8 = outs["int8"]
+    a1, W1, b1, ll1 = outs["fp64"]
+    np.testing.assert_array_equal(a8, a1)
+    np.testing.assert_allclose(W8, W1, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(b8, b1, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(ll8, ll1, rtol=1e-12)
+    assert np.all(W1[~a1] == 0)
+    if rho < 1.0:
+        assert not np.array_equal(a1, a) and 0.05 * N < a1[0].sum() < 0.98 * N
+    for i in (0, nloc - 1):
+        M = torch.tril(eng.Jbuf[i, :D + 2, :D + 2])
+        idx = torch.nonzero(torch.from_numpy(np.concatenate((np.repeat(a1[i], B), [True]))).cuda())[:, 0]
+        k = idx.numel()
+        Js = M[:D + 1, :D + 1][idx][:, idx]
+        Js = Js + torch.tril(Js, -1).t()
+        h = M[D + 1, :D + 1][idx]
+        del M
+        mu = torch.cholesky_solve(h[:, None], torch.linalg.cholesky(Js))[:, 0]
+        d = torch.from_numpy(np.concatenate((W1[i][a1[i]].ravel(), [b1[i]]))).cuda() - mu
+        zz = float(z[i, :k] @ z[i, :k])
+        assert abs((d @ (Js @ d)).item() / zz - 1) < 1e-8                                   # the draw: x - mu = L^-T z
+        if rho < 1.0:
+            low = torch.tril(eng.Mtab[i, :D + 1, :D + 1])
+            Ms = low[idx][:, idx]
+            del low
+            Ms = Ms + torch.tril(Ms, -1).t()
+            v = torch.from_numpy(np.random.default_rng(3).standard_normal(k)).cuda()
+            assert (Js @ (Ms @ v) + v).abs().max().item() < 1e-8 * v.abs().max().item()     # tableau: M_SS = -J_SS^-1
+            del Ms
+        del Js
+    # z = 0: the draw is the posterior mean, J_SS mu = h_S
+    a2, W2, b2, _ = eng.sweep(a, W, b, rho_a, *hyp, perm, u, np.zeros_like(z), seed=seed, sweep=0)
+    np.testing.assert_array_equal(a2, a1)
+    Jp, hp = eng.posterior(0)
+    m = np.concatenate((np.repeat(a2[0], B), [True]))
+    mu = np.concatenate((W2[0][a2[0]].ravel(), [b2[0]]))
+    assert np.abs(Jp[np.ix_(m, m)] @ mu - hp[m]).max() <= 1e-8 * np.abs(hp[m]).max()
+    del eng
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_full_size_sweep_int8_equals_fp64():
+    """BASELINE.json configs[2] -- the metric's own configuration, N = 1024, B = 5, T = 100 000 -- on an 8-neuron shard"""
+    _fullsize_sweep_checks("bernoulli", 1024, 5, 100000, 8, rho=0.5, S_w=1e-3)
+
+
+def test_cfg4_full_size_sweep_int8_equals_fp64():
+    """BASELINE.json configs[3]: NegativeBinomialGLM N = 512, B = 5, T = 100 000 (PG shape b = y + xi; dense prior: rho = 1, no flips)
+    on an 8-neuron shard"""
+    _fullsize_sweep_checks("negbin", 512, 5, 100000, 8, rho=1.0, S_w=1.0, xi=2.0)

@@ -250,27 +250,37 @@ def test_long_chain_matches_oracle_chain_statistically():
     assert np.abs(A1 - A2).max() < 0.35
 
 
-def _two_rank_worker(rank, world, port, out_path):
+def _two_rank_worker(rank, world, port, out_path, backend="gloo"):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
+    import torch
     import torch.distributed as dist
     from pyglm_amd.models import SparseBernoulliGLM
     from pyglm_amd.utils.basis import cosine_basis
+    dev = "cuda:0"
+    if backend == "nccl":                      # one GPU per rank, RCCL collectives: the production layout
+        dev = "cuda:%d" % rank
+        torch.cuda.set_device(rank)
     if world > 1:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        kw = dict(device_id=torch.device(dev)) if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kw)
     np.random.seed(0)
     N, B, T = 9, 2, 1200
     basis = cosine_basis(B, L=10) / 10
     Y = (np.random.rand(T, N) < 0.2).astype(float)
-    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=5.0, mu_b=-1.0), seed=11, device="cuda:0")
+    model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=5.0, mu_b=-1.0), seed=11, device=dev)
     model.add_data(Y)
     lls = [model.log_likelihood()]
     for _ in range(3):
         model.resample_model()
         lls.append(model.log_likelihood())
+    Y2 = (np.random.RandomState(3).rand(300, N) < 0.2).astype(float)
+    lls.append(model.log_likelihood([Y2]))        # held-out data: a likelihood-only engine on this rank's own device
+    lls.append(model.log_likelihood([Y2]))        # (second call: served from the content-keyed cache)
+    assert model._heldout_cache[1].dev == model.engine.dev and torch.cuda.current_device() == model.engine.dev.index
     if rank == 0:
         np.savez(out_path, A=model.adjacency, W=model.weights, b=model.biases, lls=np.array(lls), means=model.means[0])
     else:
@@ -294,8 +304,64 @@ def test_two_processes_sharing_the_gpu_equal_one(tmp_path):
     mp.spawn(_two_rank_worker, args=(1, 0, one), nprocs=1, join=True)
     mp.spawn(_two_rank_worker, args=(2, port, two), nprocs=2, join=True)
     a, b = np.load(one), np.load(two)
+    assert a["lls"][-1] == a["lls"][-2]
     for k in a.files:
         if k == "lls":
             np.testing.assert_allclose(a[k], b[k], rtol=1e-13)      # sum over neurons in a different grouping
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.timeout(900)
+def test_two_gpus_over_rccl_equal_one(tmp_path):
+    """the production layout -- one process per GPU, torch.distributed backend "nccl" (= RCCL) -- with 2 ranks on 2 GPUs, against one
+    rank: bit-equal state, means and (to summation order) log-likelihoods.  Needs two GPUs; skipped on a one-GPU box."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (device_count() = %d)" % torch.cuda.device_count())
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_two_rank_worker, args=(1, 0, one, "nccl"), nprocs=1, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, two, "nccl"), nprocs=2, join=True)
+    a, b = np.load(one), np.load(two)
+    for k in a.files:
+        if k == "lls":
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-13)
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_standalone_regression_cache_is_keyed_by_content():
+    """reg.mean(X_train) then reg.mean(X_test) with equal shapes must not return the first result again (the engine cache used to be
+    keyed by id(), which CPython reuses for temporaries); data edited in place is uploaded again; equal data is served from the cache"""
+    from pyglm_amd.regression import SparseBernoulliRegression
+    np.random.seed(5)
+    N, B, T = 4, 3, 50
+    reg = SparseBernoulliRegression(N, B, rho=1.0, S_w=1.0)
+    want = lambda X: orc.logistic(X.reshape(T, -1) @ (reg.a[:, None] * reg.W).ravel() + reg.b[0])
+    for trial in range(4):
+        X1 = np.random.randn(T, N, B)           # 3-D input: _flatten_X makes a temporary view
+        X2 = np.random.randn(T, N, B)
+        np.testing.assert_allclose(reg.mean(X1), want(X1), rtol=1e-10)
+        np.testing.assert_allclose(reg.mean(X2), want(X2), rtol=1e-10)
+    eng = reg._lik_engine_cache[1]
+    np.testing.assert_allclose(reg.mean(X2.copy()), want(X2), rtol=1e-10)
+    assert reg._lik_engine_cache[1] is eng                                  # same content: no new upload
+    X2[7] += 1.0                                                             # in-place edit
+    np.testing.assert_allclose(reg.mean(X2), want(X2), rtol=1e-10)
+    assert reg._lik_engine_cache[1] is not eng
+    y = (np.random.rand(T) < 0.3).astype(float)
+    ll = reg.log_likelihood((X1, y))
+    psi = X1.reshape(T, -1) @ (reg.a[:, None] * reg.W).ravel() + reg.b[0]
+    np.testing.assert_allclose(ll, y * psi - np.log1p(np.exp(psi)), rtol=1e-9, atol=1e-12)
+    reg.resample([(X1, y)], seed=3)
+    eng = reg._engine_cache[1]
+    reg.resample([(X1, y)], seed=3, sweep=1)
+    assert reg._engine_cache[1] is eng
+    reg.resample([(X1, 1.0 - y)], seed=3, sweep=2)                           # different spikes, same X
+    assert reg._engine_cache[1] is not eng

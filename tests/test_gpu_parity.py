@@ -139,6 +139,46 @@ def test_regression_resample_golden(torch_dev, golden, tag, gram):
     np.testing.assert_allclose(b1, g[tag + "_b1"], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("tag", ["c0", "c1", "c2"])
+def test_flip_logodds_golden(torch_dev, golden, tag):
+    """(a) the log-odds of the golden resample() against the oracle's replay of it (the oracle reproduces the reference's decisions and
+    `_marginal_likelihood` values: tests/test_oracle_golden.py);  (b) against the REFERENCE's own `_marginal_likelihood` numbers
+    (regression.py:343-378, fixture G6): walking the adjacency row from mask i to mask i+1 with forced decisions, the log-odds of the
+    steps that flip telescope to ml(mask i+1) - ml(mask i)."""
+    g = golden
+    N, B = g[tag + "_mu_w"].shape
+    r = orc.Regression(N, B, rho=g[tag + "_rho"], mu_w=g[tag + "_mu_w"], S_w=g[tag + "_S_w"], mu_b=g[tag + "_mu_b"], S_b=g[tag + "_S_b"])
+    eng = _engine(N, B, 0, 1)
+    datas = [(g[tag + "_X"], g[tag + "_y"]), (g[tag + "_X2"], g[tag + "_y2"])]
+    for X, y in datas:
+        Y = np.zeros((len(y), N))
+        Y[:, 0] = y
+        eng.add_data(Y, X=X)
+    a0, W0, b0 = g[tag + "_a0"][None], g[tag + "_W0"][None], g[tag + "_b0"]
+    rho, Jw, hw, Jb, hb, c0 = _hyp([r])
+    oms = [g[tag + "_om1"][:, None], g[tag + "_om2"][:, None]]
+    eng.keep_logodds = True
+    a1, _, _, _ = eng.sweep(a0, W0, b0, rho, Jw, hw, Jb, hb, c0, g[tag + "_perm"][None], g[tag + "_u"][None], g[tag + "_z"][None],
+                            seed=1, sweep=0, omega_override=oms)
+    np.testing.assert_array_equal(a1[0], g[tag + "_a1"])
+    r.a, r.W, r.b = a0[0].copy(), W0[0].copy(), b0.copy()
+    trace = []
+    r.resample(datas, [g[tag + "_om1"], g[tag + "_om2"]], g[tag + "_perm"], g[tag + "_u"], g[tag + "_z"], trace=trace)
+    _check_logodds(eng, [(None, None, None, trace)])
+    # (b) telescoping sums against the reference's marginal likelihoods; rho = 1/2 makes the prior-odds term vanish
+    masks, mls = g[tag + "_ml_masks"].astype(bool), g[tag + "_ml"]
+    half = np.full((1, N), 0.5)
+    perm = np.arange(N, dtype=np.int32)[None]
+    for i in range(len(masks) - 1):
+        src, dst = masks[i], masks[i + 1]
+        u = np.where(dst, 1.0 - 1e-15, 0.0)[None]                       # sample_discrete_from_log then returns dst[m] (if |log-odds| < 34)
+        a2, _, _, _ = eng.sweep(src[None], W0, b0, half, Jw, hw, Jb, hb, c0, perm, u, g[tag + "_z"][None], seed=1, sweep=0, omega_override=oms)
+        lo = eng.logodds.cpu().numpy()[0]
+        assert np.all(np.abs(lo) < 34.0) and np.array_equal(a2[0], dst), (tag, i)
+        total = lo[dst & ~src].sum() - lo[src & ~dst].sum()
+        np.testing.assert_allclose(total, mls[i + 1] - mls[i], rtol=1e-10, atol=1e-9)
+
+
 @pytest.mark.parametrize("gram", ["fp64", "int8"])
 def test_model_sweep_golden(torch_dev, golden, gram):
     g = golden
@@ -175,6 +215,22 @@ def _random_problem(N, B, T, seed, rho=0.5, p_spike=0.1, n_active_true=3):
     return basis, X, Y2, rng
 
 
+def _check_logodds(eng, outs, rows=None):
+    """the flip log-odds the kernel formed (lps[1] - lps[0] of regression.py:293-307, exported per proposal step) against the oracle's
+    trace: bit-equal decisions only bound their error to ~1e-3, so the numbers themselves are compared (1e-9 absolute + 1e-10 relative)"""
+    lo = eng.logodds.cpu().numpy()
+    for n, out in enumerate(outs):
+        if rows is not None and n not in rows:
+            continue
+        trace = out[3]
+        want = np.array([t[1] for t in trace])
+        got = lo[n, :len(trace)]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), n            # rho in {0, 1}: 0 log 0 = NaN on both sides
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-10, atol=1e-9, err_msg="log-odds of row %d" % n)
+        assert np.isnan(lo[n, len(trace):]).all()                          # no proposals beyond the trace
+
+
 def _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z):
     outs = []
     for n in range(N):
@@ -199,6 +255,7 @@ def test_sweep_vs_oracle(torch_dev, N, B, T, rho, batch):
     regs = [orc.Regression(N, B, **kw) for _ in range(N)]
     rho_a, Jw, hw, Jb, hb, c0 = _hyp(regs)
     perm, u, z = make_draws(123, 4, range(N), N, N * B)
+    eng.keep_logodds = True
     a1, W1, b1, _ = eng.sweep(a, W, b, rho_a, Jw, hw, Jb, hb, c0, perm, u, z, seed=123, sweep=4)
     omegas = eng.datasets[0].OK[:T, :N].cpu().numpy()
     # the PG draws themselves: against the oracle on the same stream
@@ -213,6 +270,7 @@ def test_sweep_vs_oracle(torch_dev, N, B, T, rho, batch):
         np.testing.assert_array_equal(a1[n], ao, err_msg="adjacency row %d" % n)
         np.testing.assert_allclose(W1[n], Wo, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(b1[n], bo[0], rtol=1e-7, atol=1e-9)
+    _check_logodds(eng, outs)
     # the flips really were exercised
     if rho < 1:
         assert (a1 != a).sum() > 0
@@ -236,6 +294,7 @@ def test_sweep_vs_oracle_large_initial_active_set(torch_dev):
     regs = [orc.Regression(N, B, **kw) for _ in range(N)]
     rho_a, Jw, hw, Jb, hb, c0 = _hyp(regs)
     perm, u, z = make_draws(77, 1, range(N), N, N * B)
+    eng.keep_logodds = True
     a1, W1, b1, _ = eng.sweep(a, W, b, rho_a, Jw, hw, Jb, hb, c0, perm, u, z, seed=77, sweep=1)
     omegas = eng.datasets[0].OK[:T, :N].cpu().numpy()
     outs = _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z)
@@ -243,6 +302,7 @@ def test_sweep_vs_oracle_large_initial_active_set(torch_dev):
         np.testing.assert_array_equal(a1[n], ao, err_msg="adjacency row %d" % n)
         np.testing.assert_allclose(W1[n], Wo, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(b1[n], bo[0], rtol=1e-7, atol=1e-9)
+    _check_logodds(eng, outs)
     assert (a1 != a).sum() > 100
 
 
@@ -324,6 +384,7 @@ def test_edge_shapes_vs_oracle(torch_dev, N, B, T, rho):
     regs = [orc.Regression(N, B, **kw) for _ in range(N)]
     hyp = _hyp(regs)
     perm, u, z = make_draws(77, 1, range(N), N, N * B)
+    eng.keep_logodds = True
     a1, W1, b1, ll = eng.sweep(a, W, b, *hyp, perm, u, z, seed=77, sweep=1)
     om = eng.datasets[0].OK[:T, :N].cpu().numpy()
     outs = _oracle_sweep(N, B, X, Y, a, W, b, kw, om, perm, u, z)
@@ -331,6 +392,7 @@ def test_edge_shapes_vs_oracle(torch_dev, N, B, T, rho):
         np.testing.assert_array_equal(a1[n], ao)
         np.testing.assert_allclose(W1[n], Wo, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(b1[n], bo[0], rtol=1e-7, atol=1e-9)
+    _check_logodds(eng, outs)
     if rho == 0.0:
         assert not a1.any() and np.all(W1 == 0)
 

@@ -105,7 +105,12 @@ def test_network_prior_shapes_and_niw_update():
     W = np.random.randn(N, N, B)
     net.resample((A, W))
     assert np.all(NIWDenseNetwork(N, B).rho == 1)
-    assert FixedMeanSparseNetwork(N, B, mu=0.5, sigma=2.0, rho=0.2).sigma_W[0, 1, 1, 1] == 2.0
+    from pyglm_amd import networks
+    networks.set_reference_quirks(False)
+    try:
+        assert FixedMeanSparseNetwork(N, B, mu=0.5, sigma=2.0, rho=0.2).sigma_W[0, 1, 1, 1] == 2.0
+    finally:
+        networks.set_reference_quirks(True)
     with pytest.raises(AssertionError):
         net.resample((A.astype(float), W))
     # posterior parameters of the NIW update equal the oracle's restatement
@@ -113,11 +118,97 @@ def test_network_prior_shapes_and_niw_update():
     ours = _NIW(np.zeros(B), np.eye(B), 1.0, 4.0)
     ref = orc.NIWGaussian(np.zeros(B), np.eye(B), 1.0, 4.0, np.random.default_rng(0))
     mu_n, sig_n, k_n, nu_n = ref.posterior(data)
-    draws = []
-    for _ in range(3000):
+    draws, sigmas = [], []
+    for _ in range(4000):
         ours.resample(data)
         draws.append(ours.mu)
-    np.testing.assert_allclose(np.mean(draws, 0), mu_n, atol=0.02)
+        sigmas.append(ours.sigma)
+    draws, sigmas = np.array(draws), np.array(sigmas)
+    np.testing.assert_allclose(draws.mean(0), mu_n, atol=0.02)
+    # second moments of the NIW posterior (published): E[Sigma] = Sigma_n / (nu_n - B - 1), Cov[mu] = E[Sigma] / kappa_n; and a
+    # Bartlett check on the scale: tr(Sigma_n Sigma^-1) ~ chi^2 with nu_n B degrees of freedom (mean nu_n B, variance 2 nu_n B)
+    ES = sig_n / (nu_n - B - 1)
+    np.testing.assert_allclose(sigmas.mean(0), ES, rtol=0.04, atol=0.004)
+    np.testing.assert_allclose(np.cov(draws.T), ES / k_n, rtol=0.1, atol=2e-3)
+    tr = np.array([np.trace(sig_n @ np.linalg.inv(S)) for S in sigmas])
+    assert abs(tr.mean() - nu_n * B) < 4 * np.sqrt(2 * nu_n * B / len(tr)) and abs(tr.var() / (2 * nu_n * B) - 1) < 0.15
+
+
+def test_network_constructors_match_the_reference(golden):
+    """fixture G12: the NIW hyper-parameters and connection probabilities the REFERENCE's constructors end up with for a set of keyword
+    arguments (most never arrive: networks.py:83, 180, 196), for B on both sides of nu_0 >= B; with set_reference_quirks(False) the
+    keywords take effect"""
+    import warnings
+    from pyglm_amd import networks
+    kw = dict(nu_0=7.0, kappa_0=3.0, mu_0=0.5, sigma_0=2.0, rho=0.2, rho_self=0.9)
+    for name, cls in (("sparse", networks.NIWSparseNetwork), ("dense", networks.NIWDenseNetwork)):
+        for B in (1, 2, 3, 5):
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                net = cls(3, B, **kw)
+            assert any("never reach" in str(x.message) for x in w)
+            g, s = net._gaussian, net._self_gaussian
+            got = np.array([g.nu_0, g.kappa_0, g.mu_0[0], g.sigma_0[0, 0], s.nu_0, s.kappa_0, s.mu_0[0], s.sigma_0[0, 0]])
+            want = golden["N_%s_B%d_niw" % (name, B)].copy()
+            if B > 3:      # nu_0 = 3 < B: the reference cannot draw from this prior at all; floored (with a warning) so that cfg2/cfg3 run
+                assert want[4] == 3.0 and got[4] == B + 2 and any("fails to construct" in str(x.message) for x in w)
+                want[4] = B + 2
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(net.rho, golden["N_%s_B%d_rho" % (name, B)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = networks.FixedMeanSparseNetwork(3, 2, mu=0.7, sigma=4.0, rho=0.3)
+    np.testing.assert_array_equal(net.mu_W, golden["N_fixed_mu"])
+    np.testing.assert_array_equal(net.sigma_W, golden["N_fixed_sigma"])
+    np.testing.assert_array_equal(net.rho, golden["N_fixed_rho"])
+    networks.set_reference_quirks(False)
+    try:
+        net = networks.NIWSparseNetwork(3, 2, **kw)
+        assert (net._gaussian.nu_0, net._self_gaussian.nu_0, net._gaussian.kappa_0, net._gaussian.mu_0[0], net.rho[0, 1], net.rho[1, 1]) == (7.0, 7.0, 3.0, 0.5, 0.2, 0.9)
+        net = networks.FixedMeanSparseNetwork(3, 2, mu=0.7, sigma=4.0, rho=0.3)
+        assert net.mu_W[0, 1, 0] == 0.7 and net.sigma_W[0, 1, 1, 1] == 4.0
+    finally:
+        networks.set_reference_quirks(True)
+
+
+def test_network_resample_and_push_match_the_reference(golden):
+    """fixture G11: the data the reference's resample_network hands to its two Gaussians (models.py:228-231, networks.py:132-149) and
+    the hyper-parameters it then pushes into every regression (models.py:233-236), with the NIW draw held at the prior parameters as in
+    the fixture (the draw itself is third-party code: see test_network_prior_shapes_and_niw_update for its distribution)"""
+    from pyglm_amd import networks
+    from pyglm_amd.models import SparseBernoulliGLM
+    from tests._oracle_engine import OracleEngine
+    g = golden
+    N, _, B = g["M_W1"].shape
+    seen = {}
+
+    class Fixed(networks._NIW):
+        def resample(self, data=()):
+            self.mu, self.sigma = self.mu_0.copy(), self.sigma_0.copy()
+            seen[id(self)] = np.array(data)
+    old = networks._NIW
+    networks._NIW = Fixed
+    try:
+        np.random.seed(3)
+        m = SparseBernoulliGLM(N, basis=g["M_basis"], regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=1, engine_factory=OracleEngine)
+    finally:
+        networks._NIW = old
+    for n, r in enumerate(m.regressions):
+        r.a, r.W, r.b = g["M_A1"][n].copy(), g["M_W1"][n].copy(), g["M_b1"][n:n + 1].copy()
+    m.resample_network()
+    np.testing.assert_array_equal(seen[id(m.network._gaussian)].reshape(-1, B), g["M_net_offdiag_data"].reshape(-1, B))
+    np.testing.assert_array_equal(seen[id(m.network._self_gaussian)].reshape(-1, B), g["M_net_diag_data"].reshape(-1, B))
+    np.testing.assert_array_equal(np.array([r.S_w for r in m.regressions]), g["M_push_S_w"])
+    np.testing.assert_array_equal(np.array([r.mu_w for r in m.regressions]), g["M_push_mu_w"])
+    np.testing.assert_array_equal(np.array([r.rho for r in m.regressions]), g["M_push_rho"])
+    # and the cached natural-parameter terms of that push are what the dense formulas give
+    from pyglm_amd.engine import prior_terms
+    _, (rho, prior, _, Jb, hb, _) = m._hyper_cache
+    Jw, hw, c0 = prior.dense()
+    want = prior_terms(g["M_push_S_w"], g["M_push_mu_w"], np.ones(N), np.full(N, -2.0))
+    np.testing.assert_allclose(Jw, want[0], rtol=1e-14)
+    np.testing.assert_allclose(c0, want[4], rtol=1e-13)
+    np.testing.assert_array_equal(rho, g["M_push_rho"])
 
 
 def test_pushed_hyper_cache_equals_dense_terms():
@@ -131,9 +222,10 @@ def test_pushed_hyper_cache_equals_dense_terms():
     m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
     m.resample_network()
     assert type(m.regressions[0]._S_w).__name__ == "_BlockRows"           # pushed as (shared block, own block), expanded only when read
+    versions, (rho, prior, _, Jb, hb, _) = m._hyper_cache
+    assert versions == tuple(r._hyp_version for r in m.regressions)
     np.testing.assert_array_equal(m.regressions[4].S_w, m.network.sigma_W[4])
     np.testing.assert_array_equal(m.regressions[4].mu_w, m.network.mu_W[4])
-    versions, (rho, prior, _, Jb, hb, _) = m._hyper_cache
     assert prior.Jw_u.shape[0] <= 3 and prior.label.shape == (N, N)      # a handful of distinct blocks, never expanded
     Jw, hw, c0 = prior.dense()
     regs = m.regressions
@@ -142,9 +234,32 @@ def test_pushed_hyper_cache_equals_dense_terms():
     for got, w in zip((Jw, hw, Jb, hb, c0), want):
         np.testing.assert_allclose(got, w, rtol=1e-13, atol=1e-15)
     np.testing.assert_array_equal(rho, np.array([r.rho for r in regs]))
-    assert versions == tuple(r._hyp_version for r in regs)
-    regs[2].S_w = 5.0
-    assert versions != tuple(r._hyp_version for r in regs)      # stale cache is detected
+    assert versions != tuple(r._hyp_version for r in regs)      # the public getters handed out live arrays: the cache counts as stale
+
+
+def test_in_place_hyper_edits_reach_the_next_sweep():
+    """`reg.rho[m] = x` edits the live array (as users of the reference do); the cached natural-parameter terms must not outlive it"""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(4)
+    N, B, T = 4, 2, 300
+    Y = (np.random.rand(T, N) < 0.2).astype(float)
+    m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
+    m.add_data(Y)
+    m.resample_model()
+    m.resample_model()                         # second sweep runs from the cache of the network push
+    assert m._hyper_cache[0] == tuple(r._hyp_version for r in m.regressions)
+    for r in m.regressions:
+        r.rho[:] = 0.0                         # in place, through the getter
+        r.rho[1] = 1.0
+    m.resample_regressions()
+    np.testing.assert_array_equal(m.adjacency, np.tile(np.array([False, True, False, False]), (N, 1)))
+    m2 = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
+    m2.add_data(Y)
+    m2.resample_regressions()
+    m2.regressions[0].S_w[2] *= 100.0          # in-place edit of a covariance block between sweeps
+    m2.resample_regressions()
+    assert m2._hyper_cache[1][1][0, 2, 0, 0] == pytest.approx(1.0 / 300.0)
 
 
 def test_api_error_behaviour_matches_reference():
@@ -262,3 +377,32 @@ def test_integer_gram_arithmetic_on_the_host():
         for qd in range(NP_ - 1, -1, -1):
             s = s * P[qd] + d[qd]
         assert s == S
+
+
+def test_chain_state_roundtrip_resumes_exactly():
+    """get_state() / set_state(): a chain resumed from a snapshot repeats the original bit for bit (random inputs are keyed by
+    (seed, sweep, neuron); the network draws by (seed, sweep))"""
+    from pyglm_amd.models import SparseBernoulliGLM, SparseGaussianGLM
+    from tests._oracle_engine import OracleEngine
+    for cls, kw in [(SparseBernoulliGLM, dict(S_w=3.0, mu_b=-1.0)), (SparseGaussianGLM, dict(S_w=3.0, a_0=2.0, b_0=1.0))]:
+        np.random.seed(4)
+        N, B, T = 4, 2, 250
+        Y = (np.random.rand(T, N) < 0.2).astype(float) + (0.3 * np.random.randn(T, N) if cls is SparseGaussianGLM else 0.0)
+        m = cls(N, B=B, regression_kwargs=kw, seed=7, engine_factory=OracleEngine)
+        m.add_data(Y)
+        for _ in range(2):
+            m.resample_model()
+        st = m.get_state()
+        for _ in range(2):
+            m.resample_model()
+        first = (m.adjacency.copy(), m.weights.copy(), m.biases.copy(), m.log_likelihood())
+        for r in m.regressions:
+            r.W[:] = 5.0                                    # (later edits must not reach the snapshot)
+        m.set_state(st)
+        assert m.sweeps_done == 2 and not np.any(m.weights == 5.0)
+        for _ in range(2):
+            m.resample_model()
+        np.testing.assert_array_equal(m.adjacency, first[0])
+        np.testing.assert_array_equal(m.weights, first[1])
+        np.testing.assert_array_equal(m.biases, first[2])
+        assert m.log_likelihood() == first[3]
