@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 2
+#define PGL_ABI_VERSION 3
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -172,6 +172,78 @@ typedef struct {
 } pgl_chol_t;
 int pgl_active_index(const pgl_chol_t* s, void* hip_stream);                  /* fills act / na */
 int pgl_sample_weights(const pgl_chol_t* s, int na_max, void* hip_stream);    /* na_max >= max_n na[n] (read back by the caller) */
+
+/* ---- one Gibbs sweep of a shard of neurons in ONE call ------------------------------------------------------------------------
+ * Replaces the loop `for n in range(N): regressions[n].resample(...)` at pyglm/models.py:169-171 with the body pyglm/regression.py:265-280
+ * for the nloc postsynaptic neurons [n0, n0 + nloc) of one GPU: activation (:195-201), PG draw / kappa / log-likelihood (:491-511),
+ * likelihood statistics (:225-262), prior statistics (:210-223), collapsed flips (:282-320 with :343-378), weight draw (:323-340).
+ * The call only queues work on the stream -- no host synchronisation, nothing decided on the host between launches -- so it returns
+ * in milliseconds; pgl_get_state (or any later synchronisation of the stream) waits for it.  All pointers are device pointers owned by
+ * the caller.  Dimensions: D = N B, (Dp, ldn, ldj) from pgl_sweep_dims, kmax = pgl_flip_kmax().  Batches of nb neurons share the
+ * `[nb]...` scratch; the chain state (a, W, b) lives on the device and is updated in place. */
+typedef struct {
+    int T, Tp;                     /* time bins; rows of the padded arrays, Tp % 16 == 0 */
+    const double* X;               /* [Tp][Dp]  design matrix, column D = 1 (bias regressor), padding 0 (pgl_design_matrix) */
+    const double* Xt;              /* [Dp][Tp]  its transpose */
+    const double* Y;               /* [T][ldn]  counts of the local neurons */
+    double* Psi;                   /* [T][ldn]  out: activations */
+    double* OK;                    /* [Tp][2 ldn]  out: [Omega | Kappa]; rows >= T must be zero (and stay zero) */
+    double* llpart;                /* [pgl_pg_loglik_partials(T)][nloc] scratch */
+    uint64_t elem0;                /* PG stream element of the first bin: sum of T of the data sets before this one */
+    int int8;                      /* 1: likelihood Gram on the integer matrix cores (sA, PA valid); 0: fp64 MFMA kernel */
+    const double* sA;              /* [D] column scales of X (pgl_i8_scales) */
+    const void* PA;                /* residue planes of X (pgl_i8_planes), `planes` of them */
+    const double* omega_override;  /* optional [T][nloc]: replaces the PG draws (test hook: the reference fixtures inject omega) */
+} pgl_dataset_t;
+
+#define PGL_NSTAGES 16
+typedef struct {                   /* host; zero-initialise.  Per stage (pgl_stage_name): HIP-event time on the launch stream, calls, work */
+    double ms[PGL_NSTAGES];
+    double work[PGL_NSTAGES];
+    int calls[PGL_NSTAGES];
+    void* pending;                 /* events recorded by pgl_sweep and not yet folded in by pgl_stage_times_collect */
+} pgl_stage_times_t;
+
+typedef struct {
+    int N, B, n0, nloc, nb;        /* neurons, basis functions, first local neuron (global index), local neurons, neurons per batch */
+    int obs; double xi;            /* 0 Bernoulli, 1 negative binomial (b = y + xi), 2 Gaussian */
+    int visit_order;               /* 1: sweep tableau in proposal order (see pgl_flip_t) */
+    int planes, i8_group;          /* integer Gram: moduli in use, neurons per launch (<= 8) */
+    const pgl_dataset_t* datasets; int ndatasets;      /* host array */
+    int* a; double* W; double* b;  /* chain state, in/out: [nloc][N] (0/1), [nloc][D] (zeros where a = 0), [nloc] */
+    const double* rho;             /* [nloc][N] */
+    const double* Jw; const double* hw; const int* label;   /* prior blocks: dense [nloc][N][B][B] / [nloc][N][B] with label = NULL, or
+                                    * tables [K][B][B] / [K][B] with label [nloc][N] (see pgl_assemble_posterior) */
+    const double* Jb; const double* hb;                /* [nloc] */
+    const double* c0;              /* [nloc][N] (label = NULL) or table [K]: 1/2 log|J_w| - 1/2 mu_w' J_w mu_w of the block */
+    const int* perm; const double* u; const double* z; /* [nloc][N], [nloc][N], [nloc][D + 1]: permutation, uniforms, normals (see pgl_flip_t, pgl_chol_t) */
+    const double* inv_eta; const double* G0;           /* Gaussian model only: [nloc], [ldj][ldj] = X'X */
+    double* ll;                    /* out [nloc]: log-likelihood (Gaussian: sum of squared residuals) under the state BEFORE the sweep */
+    int* status;                   /* out [nloc]: sticky flags, see pgl_flip_t */
+    double* logodds;               /* optional out [nloc][N], see pgl_flip_t */
+    /* scratch */
+    double* Wt; double* bias; double* border; int* skip; double* c0_dense;   /* [Dp][ldn], [nloc], [2 ldn][Dp], [nloc], [nloc][N] (label only) */
+    double* Jbuf; double* Mtab; double* Ac;            /* [nb][ldj][ldj] each */
+    double* hc; double* Tinv; double* G; double* Lws;  /* [2][nb][ldj], [nb][64][64], [nb][kmax][kmax], [nb][(kmax + 1)^2] */
+    double* Ut; double* Wt_ws;     /* [nb][kmax][ldj] each */
+    int* d_idx; double* d_sign; int* d_cnt; int* batch_k;   /* [nb][kmax], [nb][kmax], [nb], [nb] */
+    int* act; int* na;             /* [nb][D + 1], [nb] */
+    void* i8_PB; void* i8_R; double* i8_stat;          /* integer Gram: i8_group * pgl_i8_plane_bytes, i8_group * pgl_i8_residue_bytes (each
+                                    * * planes / 15 suffices), [3][i8_group][D] */
+    /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */
+    int all_deterministic;         /* 1: the caller knows every row has rho in {0, 1} (regression.py:153-155): the flip stage is not launched */
+    int init_rows_bound;           /* upper bound of 1 + B * (active blocks of any local neuron) BEFORE the sweep */
+    int active_rows_bound;         /* upper bound of the same AFTER the flips (only known when all_deterministic) */
+    pgl_stage_times_t* times;      /* optional (host): stage timing */
+} pgl_sweep_t;
+
+int pgl_sweep_dims(int N, int B, int nloc, int* Dp, int* ldn, int* ldj);
+int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_stream);
+/* copies the shard's state to host buffers (any may be NULL) and waits for the stream: a [nloc][N], W [nloc][D], b, ll, status [nloc].
+ * The read-backs of pyglm/models.py:54-64 (weights / adjacency / biases) for a non-Python binder. */
+int pgl_get_state(const pgl_sweep_t* s, int* a_host, double* W_host, double* b_host, double* ll_host, int* status_host, void* hip_stream);
+const char* pgl_stage_name(int i);
+int pgl_stage_times_collect(pgl_stage_times_t* t);    /* waits for the recorded events and adds them to ms / calls / work */
 
 #ifdef __cplusplus
 }

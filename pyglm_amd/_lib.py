@@ -22,6 +22,30 @@ class CholState(ctypes.Structure):   # pgl_chol_t
                 ("W", c_p), ("b", c_p), ("nb", c_i), ("N", c_i), ("B", c_i), ("status", c_p)]
 
 
+class Dataset(ctypes.Structure):     # pgl_dataset_t
+    _fields_ = [("T", c_i), ("Tp", c_i), ("X", c_p), ("Xt", c_p), ("Y", c_p), ("Psi", c_p), ("OK", c_p), ("llpart", c_p), ("elem0", c_u64),
+                ("int8", c_i), ("sA", c_p), ("PA", c_p), ("omega_override", c_p)]
+
+
+NSTAGES = 16
+
+
+class StageTimes(ctypes.Structure):  # pgl_stage_times_t
+    _fields_ = [("ms", c_d * NSTAGES), ("work", c_d * NSTAGES), ("calls", c_i * NSTAGES), ("pending", c_p)]
+
+
+class Sweep(ctypes.Structure):       # pgl_sweep_t
+    _fields_ = [("N", c_i), ("B", c_i), ("n0", c_i), ("nloc", c_i), ("nb", c_i), ("obs", c_i), ("xi", c_d), ("visit_order", c_i),
+                ("planes", c_i), ("i8_group", c_i), ("datasets", ctypes.POINTER(Dataset)), ("ndatasets", c_i),
+                ("a", c_p), ("W", c_p), ("b", c_p), ("rho", c_p), ("Jw", c_p), ("hw", c_p), ("label", c_p), ("Jb", c_p), ("hb", c_p), ("c0", c_p),
+                ("perm", c_p), ("u", c_p), ("z", c_p), ("inv_eta", c_p), ("G0", c_p), ("ll", c_p), ("status", c_p), ("logodds", c_p),
+                ("Wt", c_p), ("bias", c_p), ("border", c_p), ("skip", c_p), ("c0_dense", c_p),
+                ("Jbuf", c_p), ("Mtab", c_p), ("Ac", c_p), ("hc", c_p), ("Tinv", c_p), ("G", c_p), ("Lws", c_p), ("Ut", c_p), ("Wt_ws", c_p),
+                ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("act", c_p), ("na", c_p),
+                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p),
+                ("all_deterministic", c_i), ("init_rows_bound", c_i), ("active_rows_bound", c_i), ("times", ctypes.POINTER(StageTimes))]
+
+
 # symbol -> argument types; every function returns int status unless noted. Mirrors include/pyglm_hip.h 1:1.
 SIGNATURES = {
     "pgl_abi_version": [],
@@ -55,11 +79,16 @@ SIGNATURES = {
     "pgl_flip_apply_window": [ctypes.POINTER(FlipState), c_i, c_p],
     "pgl_flip_visit_order": [ctypes.POINTER(FlipState), c_p, c_l, c_l, c_p],
     "pgl_flip_decide": [ctypes.POINTER(FlipState), c_i, c_p],
+    "pgl_sweep_dims": [c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
+    "pgl_sweep": [ctypes.POINTER(Sweep), c_u64, c_u64, c_p],
+    "pgl_get_state": [ctypes.POINTER(Sweep), c_p, c_p, c_p, c_p, c_p, c_p],
+    "pgl_stage_name": [c_i],
+    "pgl_stage_times_collect": [ctypes.POINTER(StageTimes)],
     "pgl_active_index": [ctypes.POINTER(CholState), c_p],
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -79,7 +108,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the export is missing
         fn.argtypes = args
-        fn.restype = (ctypes.c_char_p if name == "pgl_last_error" else ctypes.c_size_t if name in ("pgl_i8_plane_bytes", "pgl_i8_residue_bytes")
+        fn.restype = (ctypes.c_char_p if name in ("pgl_last_error", "pgl_stage_name") else ctypes.c_size_t if name in ("pgl_i8_plane_bytes", "pgl_i8_residue_bytes")
                       else ctypes.c_int)
     if lib.pgl_abi_version() != ABI_VERSION:
         raise PglError("libpyglm_hip.so ABI version %d != %d (rebuild: make -C pyglm_amd/csrc)" % (lib.pgl_abi_version(), ABI_VERSION))

@@ -47,47 +47,6 @@ int pgl_grow_dynamic_lds(const void* fn, size_t bytes, PglPerDeviceSize& have) {
     return PGL_OK;
 }
 
-// kernels' host launchers (other translation units)
-int pgl_k_philox_words(uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint32_t*, size_t, hipStream_t);
-int pgl_k_pg_draw(const double*, const double*, double*, size_t, uint64_t, uint64_t, uint64_t, hipStream_t);
-int pgl_k_pg_loglik(double*, long, const double*, const double*, long, double*, long, double*, long, double*, double*, int, int, int, int, double,
-                    uint64_t, uint64_t, uint64_t, uint64_t, hipStream_t);
-int pgl_k_pg_loglik_nblk(int);
-int pgl_k_gaussian_stats(double*, long, const double*, const double*, long, const double*, double*, long, double*, long, double*, double*, int, int,
-                         int, hipStream_t);
-int pgl_k_scaled_gram(const double*, long, const double*, double*, long, long, int, int, hipStream_t);
-int pgl_k_basis_conv(const double*, long, const double*, double*, long, double*, long, int, int, int, int, int, hipStream_t);
-int pgl_k_transpose(const double*, long, double*, long, int, int, hipStream_t);
-int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const int*, const double*,
-                        const double*, int, int, int, hipStream_t);
-size_t pgl_k_i8_plane_bytes(int, int);
-size_t pgl_k_i8_residue_bytes(int);
-int pgl_k_i8_max_planes(void);
-int pgl_k_i8_min_planes(int);
-int pgl_k_i8_nu(int, int);
-int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
-int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
-int pgl_k_i8_planes(const double*, long, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);
-int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, int, int, int, int, hipStream_t);
-int pgl_k_i8_crt(const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
-struct PglFlipState {
-    double* M; long ldj; long strideM; int nb, N, B;
-    const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
-    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
-    int permuted; double* logodds;
-};
-int pgl_k_flip_apply(const PglFlipState&, int, int, int, hipStream_t);
-int pgl_k_flip_permute(const PglFlipState&, const double*, long, long, hipStream_t);
-int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);
-int pgl_k_flip_kmax(void);
-int pgl_k_flip_window_blocks(int);
-struct PglCholState {
-    const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
-    double* Ac; long ldc; long strideC; double* hc; double* Tinv; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
-};
-int pgl_k_chol_index(const PglCholState&, hipStream_t);
-int pgl_k_chol_sample(const PglCholState&, int, hipStream_t);
-
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" {

@@ -210,10 +210,6 @@ __global__ __launch_bounds__(256) void solve_sample_kernel(CholArgs g) {
 
 }  // namespace
 
-struct PglCholState {
-    const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
-    double* Ac; long ldc; long strideC; double* hc; double* Tinv; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
-};
 
 static CholArgs mk(const PglCholState& s) {
     return CholArgs{s.J, s.ldj, s.strideJ, s.a, s.act, s.ldact, s.na, s.Ac, s.ldc, s.strideC, s.hc, s.Tinv, s.z, s.ldz, s.W, s.b, s.N, s.B, s.status};

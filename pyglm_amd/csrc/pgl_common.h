@@ -68,3 +68,48 @@ enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
 // 8 zeroed per-XCD work counters for one persistent launch on stream st (a ring of slots owned by the library; pgl_gemm.hip)
 int* pgl_sched_slot(hipStream_t st);
+
+// ---- host-side views of the C-ABI structs (pgl_flip_t / pgl_chol_t of include/pyglm_hip.h), shared by the translation units
+struct PglFlipState {
+    double* M; long ldj; long strideM; int nb, N, B;
+    const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
+    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
+    int permuted; double* logodds;
+};
+struct PglCholState {
+    const double* J; long ldj; long strideJ; const int* a; int* act; long ldact; int* na;
+    double* Ac; long ldc; long strideC; double* hc; double* Tinv; const double* z; long ldz; double* W; double* b; int nb, N, B; int* status;
+};
+
+// kernels' host launchers (defined next to their kernels)
+int pgl_k_philox_words(uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint32_t*, size_t, hipStream_t);
+int pgl_k_pg_draw(const double*, const double*, double*, size_t, uint64_t, uint64_t, uint64_t, hipStream_t);
+int pgl_k_pg_loglik(double*, long, const double*, const double*, long, double*, long, double*, long, double*, double*, int, int, int, int, double,
+                    uint64_t, uint64_t, uint64_t, uint64_t, hipStream_t);
+int pgl_k_pg_loglik_nblk(int);
+int pgl_k_gaussian_stats(double*, long, const double*, const double*, long, const double*, double*, long, double*, long, double*, double*, int, int,
+                         int, hipStream_t);
+int pgl_k_scaled_gram(const double*, long, const double*, double*, long, long, int, int, hipStream_t);
+int pgl_k_basis_conv(const double*, long, const double*, double*, long, double*, long, int, int, int, int, int, hipStream_t);
+int pgl_k_transpose(const double*, long, double*, long, int, int, hipStream_t);
+int pgl_k_assemble_post(double*, long, long, const double*, const double*, long, const double*, const double*, const int*, const double*,
+                        const double*, int, int, int, hipStream_t);
+size_t pgl_k_i8_plane_bytes(int, int);
+size_t pgl_k_i8_residue_bytes(int);
+int pgl_k_i8_max_planes(void);
+int pgl_k_i8_min_planes(int);
+int pgl_k_i8_nu(int, int);
+int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
+int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
+int pgl_k_i8_planes(const double*, long, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);
+int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, int, int, int, int, hipStream_t);
+int pgl_k_i8_crt(const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
+int pgl_k_flip_apply(const PglFlipState&, int, int, int, hipStream_t);
+int pgl_k_flip_permute(const PglFlipState&, const double*, long, long, hipStream_t);
+int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);
+int pgl_k_flip_pivot_list(const PglFlipState&, int*, long, int*, hipStream_t);
+int pgl_k_flip_pivot_chunk(const PglFlipState&, const int*, long, const int*, int, int, hipStream_t);
+int pgl_k_flip_kmax(void);
+int pgl_k_flip_window_blocks(int);
+int pgl_k_chol_index(const PglCholState&, hipStream_t);
+int pgl_k_chol_sample(const PglCholState&, int, hipStream_t);

@@ -522,6 +522,56 @@ __global__ __launch_bounds__(256) void permute_tableau_kernel(FlipArgs g, const 
     }
 }
 
+// ------------------------------------------------------------------ pivot lists of the initial sweep, built on the device
+// list[n] = (bias row, then the B rows of every active block in tableau order): the set S0 = {bias} U {active blocks} the tableau is
+// first swept on, as row indices of the tableau (visit-order tableau: positions k with a[perm[k]] on, bias at D).  One workgroup per
+// neuron; the active blocks are compacted with a ballot / prefix count per 256 positions, in order -- so the list is exactly what the
+// host used to build with np.nonzero, and the chain does not depend on who builds it.
+__global__ __launch_bounds__(256) void pivot_list_kernel(FlipArgs g, int* __restrict__ list, long ldl, int* __restrict__ count) {
+    const int n = blockIdx.x, tid = threadIdx.x, N = g.N, B = g.B, D = N * B;
+    int* L = list + (long)n * ldl;
+    if (g.skip && g.skip[n]) { if (tid == 0) count[n] = 0; return; }
+    const int* a = g.a + (long)n * N;
+    const int* perm = g.perm + (long)n * N;
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    if (tid == 0) { s_base = 0; L[0] = D; }
+    __syncthreads();
+    for (int k0 = 0; k0 < N; k0 += 256) {
+        const int k = k0 + tid;
+        const int on = k < N ? (a[g.permuted ? perm[k] : k] != 0) : 0;
+        const unsigned long long bal = __ballot(on);
+        const int lane = tid & 63, wave = tid >> 6;
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (on) {
+            const int p = off + before;
+            for (int b = 0; b < B; ++b) L[1 + p * B + b] = k * B + b;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) count[n] = 1 + s_base * B;
+}
+
+// chunk c of every neuron's list -> the pending pivot list (d_idx, d_sign = +1, d_cnt)
+__global__ __launch_bounds__(256) void pivot_chunk_kernel(FlipArgs g, const int* __restrict__ list, long ldl, const int* __restrict__ count, int chunk,
+                                                          int per_chunk) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int begin = chunk * per_chunk;
+    int cnt = count[n] - begin;
+    cnt = cnt < 0 ? 0 : cnt > per_chunk ? per_chunk : cnt;
+    for (int j = tid; j < KMAX; j += 256) {
+        g.d_idx[(long)n * KMAX + j] = j < cnt ? list[(long)n * ldl + begin + j] : 0;
+        g.d_sign[(long)n * KMAX + j] = 1.0;
+    }
+    if (tid == 0) g.d_cnt[n] = cnt;
+}
+
 }  // namespace
 
 size_t pgl_k_flip_lds_decide(int B, int R) {
@@ -529,12 +579,6 @@ size_t pgl_k_flip_lds_decide(int B, int R) {
     return (2 * (size_t)nl * B + 2 * (size_t)B * B + B) * sizeof(double);
 }
 
-struct PglFlipState {
-    double* M; long ldj; long strideM; int nb, N, B;
-    const int* perm; const double* u; const double* rho; const double* c0; int* a; const int* skip;
-    int* d_idx; double* d_sign; int* d_cnt; int* batch_k; double* G; double* Lws; double* Ut; double* Wt; long ldu; int* status;
-    int permuted; double* logodds;
-};
 
 int pgl_k_flip_window_blocks(int B) {
     int r = KWIN / B;                                   // blocks per window: at most KMAX pivots ...
@@ -634,6 +678,23 @@ int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
     static PglPerDeviceSize lds_set;                      // the request depends on (B, R): raised per device when a launch needs more
     if (int rc = pgl_grow_dynamic_lds(reinterpret_cast<const void*>(decide_kernel), lds, lds_set)) return rc;
     hipLaunchKernelGGL(decide_kernel, dim3(s.nb), dim3(1024), lds, st, g, window);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_flip_pivot_list(const PglFlipState& s, int* list, long ldl, int* count, hipStream_t st) {
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, 0, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, 0, s.logodds};
+    hipLaunchKernelGGL(pivot_list_kernel, dim3(s.nb), dim3(256), 0, st, g, list, ldl, count);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+int pgl_k_flip_pivot_chunk(const PglFlipState& s, const int* list, long ldl, const int* count, int chunk, int per_chunk, hipStream_t st) {
+    if (per_chunk < 1 || per_chunk > KMAX) { pgl_set_error("pivot chunk of %d rows (max %d)", per_chunk, KMAX); return PGL_ERR_ARG; }
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, 0, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, 0, s.logodds};
+    hipLaunchKernelGGL(pivot_chunk_kernel, dim3(s.nb), dim3(256), 0, st, g, list, ldl, count, chunk, per_chunk);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

@@ -61,39 +61,55 @@ constexpr int ELEM_BITS = 50;          // |scaled element| < 2^50: the residue t
 // columns for all T (16 x 64 threads: column = tid % 16, time lane = tid / 16), so the sums are formed in a fixed order -- no atomics:
 // the scales, and with them every bit of J, do not depend on launch timing.  A NaN / inf sticks in amax (the Gram of that column is
 // then NaN, as on the fp64 kernel).
-constexpr int CS_COLS = 16, CS_LANES = 64, CS_G = 8;
+constexpr int CS_COLS = 16, CS_LANES = 64, CS_G = 8, CS_ROWS = 4;     // a pass stages CS_LANES * CS_ROWS = 256 time bins of omega
+template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const double* __restrict__ X, long ldx, const double* __restrict__ Om,
-                                                                        long ldo, int T, int D, int G, double* __restrict__ amax,
+                                                                        long ldo, int T, int D, double* __restrict__ amax,
                                                                         double* __restrict__ ss) {
+    constexpr int CH = CS_LANES * CS_ROWS;
     __shared__ double red[2][CS_LANES][CS_COLS + 1];
-    const int cl = threadIdx.x % CS_COLS, tl = threadIdx.x / CS_COLS, c = blockIdx.x * CS_COLS + cl;
-    double m[CS_G], q[CS_G];
+    __shared__ double oms[WEIGHTED ? CH : 1][WEIGHTED ? G : 1];
+    const int tid = threadIdx.x, cl = tid % CS_COLS, tl = tid / CS_COLS, c = blockIdx.x * CS_COLS + cl;
+    const bool live = c < D;
+    double m[G], q[G];
 #pragma unroll
-    for (int g = 0; g < CS_G; ++g) { m[g] = 0.0; q[g] = 0.0; }
-    if (c < D)
-        for (int t = tl; t < T; t += CS_LANES) {
-            const double x = X[(long)t * ldx + c];
+    for (int g = 0; g < G; ++g) { m[g] = 0.0; q[g] = 0.0; }
+    for (int t0 = 0; t0 < T; t0 += CH) {
+        if (WEIGHTED) {
+            __syncthreads();
+            for (int e = tid; e < CH * G; e += CS_COLS * CS_LANES) {
+                const int t = t0 + e / G;
+                oms[e / G][e % G] = t < T ? Om[(long)t * ldo + e % G] : 0.0;
+            }
+            __syncthreads();
+        }
+        double x[CS_ROWS];
 #pragma unroll
-            for (int g = 0; g < CS_G; ++g)
-                if (g < G) {
-                    const double v = Om ? x * Om[(long)t * ldo + g] : x;       // the same product the planes kernel rounds
-                    const double av = fabs(v);
-                    m[g] = av > m[g] || av != av ? av : m[g];
-                    q[g] = fma(v, v, q[g]);
-                }
+        for (int r = 0; r < CS_ROWS; ++r) {              // CS_ROWS independent loads in flight per thread
+            const int t = t0 + tl + r * CS_LANES;
+            x[r] = (live && t < T) ? X[(long)t * ldx + c] : 0.0;
         }
 #pragma unroll
-    for (int g = 0; g < CS_G; ++g) {
-        if (g >= G) break;
+        for (int r = 0; r < CS_ROWS; ++r)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const double v = WEIGHTED ? x[r] * oms[tl + r * CS_LANES][g] : x[r];       // the same product the planes kernel rounds
+                const double av = fabs(v);
+                m[g] = ((av > m[g]) | (av != av)) ? av : m[g];
+                q[g] = fma(v, v, q[g]);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
         __syncthreads();
         red[0][tl][cl] = m[g];
         red[1][tl][cl] = q[g];
         __syncthreads();
-        if (tl == 0 && c < D) {                  // one thread per column folds the 64 time lanes in order
+        if (tl == 0 && live) {                   // one thread per column folds the 64 time lanes in order
             double mm = 0.0, qq = 0.0;
             for (int k = 0; k < CS_LANES; ++k) {
                 const double v = red[0][k][cl];
-                mm = v > mm || v != v ? v : mm;
+                mm = ((v > mm) | (v != v)) ? v : mm;
                 qq += red[1][k][cl];
             }
             amax[(long)g * D + c] = mm;
@@ -483,8 +499,12 @@ size_t pgl_k_i8_residue_bytes(int D) {
 }
 
 int pgl_k_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* ss, hipStream_t st) {
-    if (G > CS_G) { pgl_set_error("i8 colstats: %d weight columns per call (max %d)", G, CS_G); return PGL_ERR_ARG; }
-    hipLaunchKernelGGL(i8_colstats_kernel, dim3((D + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, st, X, ldx, Om, ldo, T, D, G, amax, ss);
+    if (G > CS_G || G < 1) { pgl_set_error("i8 colstats: %d weight columns per call (max %d)", G, CS_G); return PGL_ERR_ARG; }
+    const dim3 grid((D + CS_COLS - 1) / CS_COLS), block(CS_COLS * CS_LANES);
+#define PGL_CS(g_) case g_: hipLaunchKernelGGL((i8_colstats_kernel<g_, true>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss); break;
+    if (!Om) hipLaunchKernelGGL((i8_colstats_kernel<1, false>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss);
+    else switch (G) { PGL_CS(1) PGL_CS(2) PGL_CS(3) PGL_CS(4) PGL_CS(5) PGL_CS(6) PGL_CS(7) PGL_CS(8) default: break; }
+#undef PGL_CS
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

@@ -1,0 +1,298 @@
+// pgl_sweep: one Gibbs sweep of a shard's regressions as ONE call -- the loop `for n in range(N): regressions[n].resample(...)` of
+// pyglm/models.py:169-171 with the body pyglm/regression.py:265-280, queued on a stream without a single host synchronisation:
+//
+//   pack a*W -> activation (regression.py:195-201) -> PG draw, kappa, log-likelihood (:491-511) -> border sums (:253-260) ->
+//   deterministic rows (:153-155, 274-275) -> per batch of neurons: omega-weighted Gram (:251-252; fp64 MFMA or exact int8 residue
+//   planes), posterior assembly (:210-223, 270-271), collapsed flips on the sweep tableau (:282-320, 343-378), weight draw (:323-340).
+//
+// Everything the host used to decide between launches is decided on the device (the pivot lists of the initial tableau sweep are built
+// from a and perm by pivot_list_kernel; the weight draw runs to the largest possible active size and stops per neuron at its own), so a
+// binder in any language gets the whole sweep from include/pyglm_hip.h, and pyglm_amd/engine.py is a thin caller of this function.
+#include "pgl_common.h"
+#include "../../include/pyglm_hip.h"
+#include <cmath>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const int* __restrict__ a, const double* __restrict__ W, const double* __restrict__ b,
+                                                           double* __restrict__ Wt, double* __restrict__ bias, int N, int B, int nloc, int Dp, int ldn) {
+    // Wt[d][n] = a[n][d / B] * W[n][d]  (k-major operand of the activation contraction); zero in the padding rows and columns
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < nloc) bias[e] = b[e];
+    if (e >= (long)Dp * ldn) return;
+    const int d = (int)(e / ldn), n = (int)(e % ldn), D = N * B;
+    double v = 0.0;
+    if (d < D && n < nloc && a[(long)n * N + d / B]) v = W[(long)n * D + d];
+    Wt[e] = v;
+}
+
+// regression.py:153-155 / 274-275: a row whose rho are all within 1e-6 of 0 or 1 is not sampled: a = round(rho), skip = 1
+__global__ __launch_bounds__(256) void deterministic_rows_kernel(const double* __restrict__ rho, int* __restrict__ a, int* __restrict__ skip, int N) {
+    const int n = blockIdx.x;
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int m = threadIdx.x; m < N; m += 256) {
+        const double r = rho[(long)n * N + m];
+        if (!((r < 1e-6) || (r > 1.0 - 1e-6))) bad = 1;
+    }
+    if (bad) s_any = 1;
+    __syncthreads();
+    const int det = !s_any;
+    if (det)
+        for (int m = threadIdx.x; m < N; m += 256) a[(long)n * N + m] = rho[(long)n * N + m] > 0.5 ? 1 : 0;
+    if (threadIdx.x == 0) skip[n] = det;
+}
+
+__global__ __launch_bounds__(256) void gather_table_kernel(const double* __restrict__ table, const int* __restrict__ label, double* __restrict__ out, long n) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = table[label[e]];
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ p, long n, double v) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) p[e] = v;
+}
+
+const char* const STAGE_NAMES[PGL_NSTAGES] = {"activation", "pg_loglik", "border", "gram", "gram.stats", "gram.planes", "gram.int8", "gram.crt",
+                                              "gram_scale", "assemble", "flips", "flips.init", "flips.decide", "flips.apply", "weights", "pack"};
+enum { ST_ACT = 0, ST_PG, ST_BORDER, ST_GRAM, ST_STATS, ST_PLANES, ST_I8, ST_CRT, ST_GSCALE, ST_ASM, ST_FLIPS, ST_FINIT, ST_FDEC, ST_FAPP, ST_W, ST_PACK };
+
+struct Pending { std::vector<std::tuple<int, hipEvent_t, hipEvent_t, double>> ev; };
+
+struct Clock {     // HIP events around a stage, on the launch stream; inert when the caller passed no pgl_stage_times_t
+    pgl_stage_times_t* t; hipStream_t st;
+    struct Mark { int stage; hipEvent_t e0; double work; bool on; };
+    Mark tic(int stage, double work = 0.0) {
+        Mark m{stage, nullptr, work, false};
+        if (!t) return m;
+        if (hipEventCreate(&m.e0) != hipSuccess) return m;
+        (void)hipEventRecord(m.e0, st);
+        m.on = true;
+        return m;
+    }
+    void toc(const Mark& m) {
+        if (!m.on) return;
+        hipEvent_t e1;
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(m.e0); return; }
+        (void)hipEventRecord(e1, st);
+        if (!t->pending) t->pending = new Pending();
+        static_cast<Pending*>(t->pending)->ev.emplace_back(m.stage, m.e0, e1, m.work);
+    }
+};
+
+inline int r_up(long x, int m) { return (int)((x + m - 1) / m * m); }
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* pgl_stage_name(int i) { return (i >= 0 && i < PGL_NSTAGES) ? STAGE_NAMES[i] : nullptr; }
+
+int pgl_sweep_dims(int N, int B, int nloc, int* Dp, int* ldn, int* ldj) {
+    PGL_CHECK_ARG(N > 0 && B > 0 && nloc > 0);
+    const long D = (long)N * B;
+    if (Dp) *Dp = r_up(D + 1, 16);
+    if (ldn) *ldn = r_up(nloc, 2);
+    if (ldj) *ldj = r_up(D + 2, 16);
+    return PGL_OK;
+}
+
+int pgl_stage_times_collect(pgl_stage_times_t* t) {
+    PGL_CHECK_ARG(t != nullptr);
+    Pending* p = static_cast<Pending*>(t->pending);
+    if (!p) return PGL_OK;
+    int rc = PGL_OK;
+    for (auto& e : p->ev) {
+        float ms = 0.f;
+        const hipEvent_t e0 = std::get<1>(e), e1 = std::get<2>(e);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { pgl_set_error("stage timing: event query failed"); rc = PGL_ERR_HIP; }
+        else { const int s = std::get<0>(e); t->ms[s] += ms; t->calls[s] += 1; t->work[s] += std::get<3>(e); }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    delete p;
+    t->pending = nullptr;
+    return rc;
+}
+
+int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    PGL_CHECK_ARG(s && s->N > 0 && s->B > 0 && s->B <= 32 && s->nloc > 0 && s->nb > 0 && s->n0 >= 0 && s->ndatasets > 0 && s->datasets);
+    PGL_CHECK_ARG(s->obs >= 0 && s->obs <= 2 && (s->obs != 1 || (s->xi > 0 && s->xi == std::floor(s->xi))));
+    PGL_CHECK_ARG(s->a && s->W && s->b && s->rho && s->Jw && s->hw && s->Jb && s->hb && s->c0 && s->perm && s->u && s->z && s->ll && s->status);
+    PGL_CHECK_ARG(s->Wt && s->bias && s->border && s->skip && s->Jbuf && s->Mtab && s->Ac && s->hc && s->Tinv && s->G && s->Lws && s->Ut && s->Wt_ws);
+    PGL_CHECK_ARG(s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->act && s->na && (s->label == nullptr || s->c0_dense != nullptr));
+    PGL_CHECK_ARG(s->obs != 2 || (s->inv_eta && s->G0));
+    const int N = s->N, B = s->B, nloc = s->nloc, nb = s->nb < nloc ? s->nb : nloc;
+    const long D = (long)N * B;
+    const int Dp = r_up(D + 1, 16), ldn = r_up(nloc, 2), ldj = r_up(D + 2, 16);
+    const long strideJ = (long)ldj * ldj;
+    const int R = pgl_k_flip_window_blocks(B);
+    if (R < 1) { pgl_set_error("B=%d too large for the proposal window", B); return PGL_ERR_ARG; }
+    bool any_i8 = false;
+    for (int i = 0; i < s->ndatasets; ++i) {
+        const pgl_dataset_t& d = s->datasets[i];
+        PGL_CHECK_ARG(d.T > 0 && d.Tp >= d.T && d.Tp % 16 == 0 && d.X && d.Xt && d.Y && d.Psi && d.OK && d.llpart);
+        PGL_CHECK_ARG(!d.int8 || (d.sA && d.PA));
+        any_i8 = any_i8 || d.int8;
+    }
+    PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= 8 && s->planes >= 1 && s->obs != 2));
+    Clock clk{s->times, st};
+
+    // ---- activation of the whole shard, PG draw / kappa / log-likelihood (regression.py:195-201, 491-511)
+    {
+        auto m = clk.tic(ST_PACK);
+        const long tot = (long)Dp * ldn;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, s->a, s->W, s->b, s->Wt, s->bias, N, B, nloc, Dp, ldn);
+        PGL_CHECK_LAUNCH();
+        clk.toc(m);
+    }
+    for (int i = 0; i < s->ndatasets; ++i) {
+        const pgl_dataset_t& d = s->datasets[i];
+        auto m = clk.tic(ST_ACT, 2.0 * d.T * D * nloc);
+        RC(pgl_activation(d.Xt, d.Tp, s->Wt, ldn, d.Psi, ldn, d.T, Dp, nloc, st));
+        clk.toc(m);
+        m = clk.tic(ST_PG, (double)d.T * nloc);
+        if (s->obs == 2) RC(pgl_k_gaussian_stats(d.Psi, ldn, s->bias, d.Y, ldn, s->inv_eta, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nloc, st));
+        else RC(pgl_k_pg_loglik(d.Psi, ldn, s->bias, d.Y, ldn, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nloc, s->obs, s->xi, seed, sweep,
+                                (uint64_t)s->n0, d.elem0, st));
+        clk.toc(m);
+        if (d.omega_override) {       // test hook: the reference fixtures inject omega
+            if (hipMemcpy2DAsync(d.OK, (size_t)2 * ldn * sizeof(double), d.omega_override, (size_t)nloc * sizeof(double), (size_t)nloc * sizeof(double),
+                                 (size_t)d.T, hipMemcpyDeviceToDevice, st) != hipSuccess) { pgl_set_error("omega override copy failed"); return PGL_ERR_HIP; }
+        }
+    }
+    // ---- border sums [Omega|Kappa]' [X, 1]  (regression.py:253-260)
+    for (int i = 0; i < s->ndatasets; ++i) {
+        const pgl_dataset_t& d = s->datasets[i];
+        auto m = clk.tic(ST_BORDER, 4.0 * d.T * (D + 1) * nloc);
+        RC(pgl_contract_tn(d.OK, 2 * ldn, 2 * ldn, d.X, Dp, Dp, s->border, Dp, 2 * ldn, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
+        clk.toc(m);
+    }
+    // ---- deterministic rows, status, optional log-odds record, block-prior constants
+    hipLaunchKernelGGL(deterministic_rows_kernel, dim3(nloc), dim3(256), 0, st, s->rho, s->a, s->skip, N);
+    PGL_CHECK_LAUNCH();
+    if (hipMemsetAsync(s->status, 0, (size_t)nloc * sizeof(int), st) != hipSuccess) { pgl_set_error("memset failed"); return PGL_ERR_HIP; }
+    if (s->logodds) {
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long)nloc * N + 255) / 256)), dim3(256), 0, st, s->logodds, (long)nloc * N, (double)NAN);
+        PGL_CHECK_LAUNCH();
+    }
+    const double* c0 = s->c0;
+    if (s->label) {
+        hipLaunchKernelGGL(gather_table_kernel, dim3((unsigned)(((long)nloc * N + 255) / 256)), dim3(256), 0, st, s->c0, s->label, s->c0_dense, (long)nloc * N);
+        PGL_CHECK_LAUNCH();
+        c0 = s->c0_dense;
+    }
+
+    for (int s0 = 0; s0 < nloc; s0 += nb) {
+        const int nbb = nb < nloc - s0 ? nb : nloc - s0;
+        // ---- likelihood Gram of neurons [s0, s0 + nbb)  (regression.py:251-252)
+        if (s->obs == 2) {
+            auto m = clk.tic(ST_GSCALE, 8.0 * nbb * D * (D + 1) / 2);
+            RC(pgl_k_scaled_gram(s->G0, ldj, s->inv_eta + s0, s->Jbuf, ldj, strideJ, (int)D, nbb, st));
+            clk.toc(m);
+        } else {
+            for (int i = 0; i < s->ndatasets; ++i) {
+                const pgl_dataset_t& d = s->datasets[i];
+                if (!d.int8) {
+                    auto m = clk.tic(ST_GRAM, (double)nbb * d.T * D * (D + 1));
+                    RC(pgl_weighted_gram(d.X, Dp, Dp, d.OK + s0, 2 * ldn, d.Tp, (int)D, nbb, s->Jbuf, ldj, strideJ, i > 0, st));
+                    clk.toc(m);
+                    continue;
+                }
+                const int G = s->i8_group, np = s->planes;
+                double* amax = s->i8_stat;
+                double* ss = s->i8_stat + (long)G * D;
+                double* sB = s->i8_stat + 2L * G * D;
+                for (int g0 = 0; g0 < nbb; g0 += G) {
+                    const int gz = G < nbb - g0 ? G : nbb - g0;
+                    const double* om = d.OK + s0 + g0;
+                    auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
+                    RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
+                    RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
+                    clk.toc(m);
+                    m = clk.tic(ST_PLANES, (double)np * gz * d.T * D);
+                    RC(pgl_k_i8_planes(d.X, Dp, om, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), d.T, (int)D, gz, np, st));
+                    clk.toc(m);
+                    m = clk.tic(ST_I8, (double)gz * d.T * D * (D + 1));
+                    RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), static_cast<const int8_t*>(s->i8_PB), static_cast<int8_t*>(s->i8_R), d.T, (int)D, gz, np, st));
+                    clk.toc(m);
+                    m = clk.tic(ST_CRT, (double)np * gz * D * (D + 1) / 2);
+                    RC(pgl_k_i8_crt(static_cast<const int8_t*>(s->i8_R), d.sA, sB, s->Jbuf + (long)g0 * strideJ, ldj, strideJ, (int)D, gz, np, i > 0, st));
+                    clk.toc(m);
+                }
+            }
+        }
+        // ---- posterior assembly (regression.py:210-223, 253-260, 270-271)
+        {
+            auto m = clk.tic(ST_ASM);
+            const double* jw = s->label ? s->Jw : s->Jw + (long)s0 * N * B * B;
+            const double* hw = s->label ? s->hw : s->hw + (long)s0 * N * B;
+            const int* lab = s->label ? s->label + (long)s0 * N : nullptr;
+            RC(pgl_k_assemble_post(s->Jbuf, ldj, strideJ, s->border + (long)s0 * Dp, s->border + (long)(ldn + s0) * Dp, Dp, jw, hw, lab, s->Jb + s0, s->hb + s0,
+                                   nbb, N, B, st));
+            clk.toc(m);
+        }
+        // ---- collapsed flips (regression.py:282-320)
+        auto mf = clk.tic(ST_FLIPS);
+        if (!s->all_deterministic) {
+            PglFlipState fs{s->Mtab, ldj, strideJ, nbb, N, B, s->perm + (long)s0 * N, s->u + (long)s0 * N, s->rho + (long)s0 * N, c0 + (long)s0 * N,
+                            s->a + (long)s0 * N, s->skip + s0, s->d_idx, s->d_sign, s->d_cnt, s->batch_k, s->G, s->Lws, s->Ut, s->Wt_ws, ldj, s->status + s0,
+                            s->visit_order ? 1 : 0, s->logodds ? s->logodds + (long)s0 * N : nullptr};
+            if (s->visit_order) RC(pgl_k_flip_permute(fs, s->Jbuf, ldj, strideJ, st));
+            else if (hipMemcpyAsync(s->Mtab, s->Jbuf, (size_t)nbb * strideJ * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                pgl_set_error("tableau copy failed"); return PGL_ERR_HIP;
+            }
+            // initial sweep on S0 = {bias} U {active blocks}, in chunks of 256 pivots; the lists come from the device
+            RC(pgl_k_flip_pivot_list(fs, s->act, D + 1, s->na, st));
+            const int ck = 256;
+            long rows = s->init_rows_bound > 0 && s->init_rows_bound <= D + 1 ? s->init_rows_bound : D + 1;
+            for (int c = 0; (long)c * ck < rows; ++c) {
+                const long left = rows - (long)c * ck;
+                auto m = clk.tic(ST_FINIT);
+                RC(pgl_k_flip_pivot_chunk(fs, s->act, D + 1, s->na, c, ck, st));
+                RC(pgl_k_flip_apply(fs, 0, (int)(left < ck ? left : ck), -1, st));
+                clk.toc(m);
+            }
+            const int nwin = (N + R - 1) / R;
+            for (int w = 0; w < nwin; ++w) {
+                auto m = clk.tic(ST_FDEC);
+                RC(pgl_k_flip_decide(fs, w, st));
+                clk.toc(m);
+                m = clk.tic(ST_FAPP);
+                RC(pgl_k_flip_apply(fs, 1, 0, w, st));
+                clk.toc(m);
+            }
+        }
+        clk.toc(mf);
+        // ---- weights (regression.py:323-340); runs to the largest possible active size, every neuron stops at its own
+        auto mw = clk.tic(ST_W);
+        PglCholState cs{s->Jbuf, ldj, strideJ, s->a + (long)s0 * N, s->act, D + 1, s->na, s->Ac, ldj, strideJ, s->hc, s->Tinv, s->z + (long)s0 * (D + 1), D + 1,
+                        s->W + (long)s0 * D, s->b + s0, nbb, N, B, s->status + s0};
+        RC(pgl_k_chol_index(cs, st));
+        long na_bound = s->active_rows_bound > 0 && s->active_rows_bound <= D + 1 ? s->active_rows_bound : D + 1;
+        RC(pgl_k_chol_sample(cs, (int)na_bound, st));
+        clk.toc(mw);
+    }
+    return PGL_OK;
+}
+
+int pgl_get_state(const pgl_sweep_t* s, int* a_host, double* W_host, double* b_host, double* ll_host, int* status_host, void* hip_stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    PGL_CHECK_ARG(s && s->nloc > 0);
+    const long D = (long)s->N * s->B;
+    auto cp = [&](void* dst, const void* src, size_t bytes) { return dst == nullptr || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess; };
+    bool ok = cp(a_host, s->a, (size_t)s->nloc * s->N * sizeof(int)) && cp(W_host, s->W, (size_t)s->nloc * D * sizeof(double)) &&
+              cp(b_host, s->b, (size_t)s->nloc * sizeof(double)) && cp(ll_host, s->ll, (size_t)s->nloc * sizeof(double)) &&
+              cp(status_host, s->status, (size_t)s->nloc * sizeof(int));
+    if (!ok || hipStreamSynchronize(st) != hipSuccess) { pgl_set_error("pgl_get_state: copy failed: %s", hipGetErrorString(hipGetLastError())); return PGL_ERR_HIP; }
+    return PGL_OK;
+}
+
+}  // extern "C"

@@ -152,6 +152,7 @@ class GibbsEngine(object):
         self.keep_logodds = False       # True: sweep() leaves the flip log-odds in self.logodds (parity tests)
         self.logodds = None
         self.profile = False
+        self._times = None              # pgl_stage_times_t filled by pgl_sweep while `profile` is on
         self._ev = []
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
@@ -179,6 +180,16 @@ class GibbsEngine(object):
             d["calls"] += 1
             d["work"] += work
         self._ev = []
+        if self._times is not None:            # the stages of pgl_sweep (HIP events recorded on the launch stream by the library)
+            call("pgl_stage_times_collect", ctypes.byref(self._times))
+            lib = _lib.load()
+            for i in range(_lib.NSTAGES):
+                if self._times.calls[i]:
+                    d = out.setdefault(lib.pgl_stage_name(i).decode(), dict(ms=0.0, calls=0, work=0.0))
+                    d["ms"] += self._times.ms[i]
+                    d["calls"] += self._times.calls[i]
+                    d["work"] += self._times.work[i]
+            self._times = None
         return out
 
     # ------------------------------------------------------------------ buffers
@@ -211,6 +222,8 @@ class GibbsEngine(object):
         self.W_dev = self._z(nl, D)
         self.b_dev = self._z(nl)
         self.status = self._z(nl, dtype=I32)
+        self.skip = self._z(nl, dtype=I32)
+        self._c0_dense = None
         self.Wt = self._z(self.Dp, self.ldn)          # k-major weights for the activation contraction
         self.bias = self._z(nl)
         self.border = self._z(2 * self.ldn, self.Dp)
@@ -377,7 +390,9 @@ class GibbsEngine(object):
         return self._ll_host(self._psi_pass(False, 0, 0))
 
     def _ll_host(self, ll_dev):
-        ll = ll_dev.cpu().numpy().copy()
+        return self._ll_host_np(ll_dev.cpu().numpy().copy())
+
+    def _ll_host_np(self, ll):
         if self.obs == 2:          # regression.py:399-403 summed over t: -T/2 log(2 pi eta) - sse / (2 eta)
             T = sum(ds.T for ds in self.datasets)
             ll = -0.5 * T * np.log(2 * np.pi * self.eta) - 0.5 * ll / self.eta
@@ -400,94 +415,95 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
     @_on_device
     def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None):
-        """regression.py:265-280 for every local neuron.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in
-        natural form (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
+        """regression.py:265-280 for every local neuron, as ONE call of pgl_sweep (include/pyglm_hip.h): the whole sweep is queued on the
+        stream without a host synchronisation.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in natural form
+        (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
         omega_override: list of (T, nloc) arrays replacing the PG draws (test hook: the reference fixtures inject omega).
-        host_overlap: optional callable run on the host once the first batch's Gram has been queued (seconds of GPU work during
-        which the host would only wait), e.g. to draw the next sweep's permutations."""
-        nloc, N, B, D, ldn, Dp, ldj = self.nloc, self.N, self.B, self.D, self.ldn, self.Dp, self.ldj
+        host_overlap: optional callable run on the host while the GPU works through the queue (seconds at full size), e.g. to draw the
+        next sweep's permutations."""
+        nloc, N, B, D = self.nloc, self.N, self.B, self.D
         if self.likelihood_only or self.design_only:
             raise _lib.PglError("this engine was built without sweep buffers (likelihood_only / design_only)")
         st = self._st()
-        a = np.asarray(a).astype(bool).copy()
+        a = np.asarray(a).astype(bool)
         rho = np.asarray(rho, dtype=np.float64)
-        det = np.all((rho < 1e-6) | (rho > 1 - 1e-6), axis=1)           # regression.py:153-155
-        self._upload_weights(a, W, b)
-        self._psi_pass(True, seed, sweep)
-        ll_before = self._ll_host(self.ll)
-        if omega_override is not None:
-            for ds, om in zip(self.datasets, omega_override):
-                ds.OK[:ds.T, :nloc] = torch.from_numpy(np.ascontiguousarray(om, dtype=np.float64)).to(self.dev)
-        # border sums  [Omega|Kappa]' [X, 1]   (regression.py:253-260)
-        for i, ds in enumerate(self.datasets):
-            h = self._tic("border", 4.0 * ds.T * (D + 1) * nloc)
-            call("pgl_contract_tn", ptr(ds.OK), 2 * ldn, 2 * ldn, ptr(ds.X), Dp, Dp, ptr(self.border), Dp, 2 * ldn, D + 1, ds.Tp,
-                 1.0, 1.0 if i > 0 else 0.0, st)
-            self._toc(h)
-        a[det] = np.round(rho[det]).astype(bool)                         # regression.py:274-275
-        a_i32 = torch.from_numpy(a.astype(np.int32)).to(self.dev)
-        self.a_dev.copy_(a_i32)
-        self.status.zero_()
-        # test hook: the log-odds of every proposal step, (nloc, N) in proposal order, NaN where no proposal was made
-        self.logodds = torch.full((nloc, N), float("nan"), dtype=F64, device=self.dev) if self.keep_logodds else None
+        det = np.all((rho < 1e-6) | (rho > 1 - 1e-6), axis=1)           # regression.py:153-155 (decided again, per row, on the device)
+        # chain state -> device
+        self.a_dev.copy_(torch.from_numpy(a.astype(np.int32)))
+        self.W_dev.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(nloc, D))))
+        self.b_dev.copy_(torch.from_numpy(np.asarray(b, dtype=np.float64).reshape(nloc)))
         label = None
         if isinstance(Jw, BlockPrior):
-            label, c0, hw, Jw = Jw.label, Jw.c0_u[Jw.label], Jw.hw_u, Jw.Jw_u
+            label, c0, hw, Jw = Jw.label, Jw.c0_u, Jw.hw_u, Jw.Jw_u        # tables + labels travel; the device gathers c0
         d = dict(rho=rho, Jw=Jw, hw=hw, Jb=Jb, hb=hb, c0=c0, perm=perm, u=u, z=z)
         dev = {}
         for k, v in d.items():
             arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
             dev[k] = torch.from_numpy(arr).to(self.dev)
         dev["label"] = None if label is None else torch.from_numpy(label).to(self.dev)
-        dev["perm_host"] = np.ascontiguousarray(perm, dtype=np.int32)
-        skip = torch.from_numpy(det.astype(np.int32)).to(self.dev)
-        # One batch after the other on the current stream.  (Running batch k's flips / weight draw on a second stream behind batch
-        # k+1's Gram was tried: bit-identical but no faster -- both stages compete for CU time, see DESIGN.md section 7.)
-        for s0 in range(0, nloc, self.nb):
-            nbb = min(self.nb, nloc - s0)
-            self._gram(s0, nbb, 0)
-            if host_overlap is not None and s0 == 0:
-                host_overlap()
-            self._post(s0, nbb, 0, a, det, dev, skip)
-        torch.cuda.synchronize(self.dev)
-        status = self.status.cpu().numpy()
+        self.logodds = torch.empty((nloc, N), dtype=F64, device=self.dev) if self.keep_logodds else None
+        if label is not None and (self._c0_dense is None):
+            self._c0_dense = self._z(nloc, N)
+        keep = [dev]
+        dsets = (_lib.Dataset * len(self.datasets))()
+        for i, ds in enumerate(self.datasets):
+            ov = None
+            if omega_override is not None:
+                ov = torch.from_numpy(np.ascontiguousarray(omega_override[i], dtype=np.float64).reshape(ds.T, nloc)).to(self.dev)
+                keep.append(ov)
+            dsets[i] = _lib.Dataset(ds.T, ds.Tp, ptr(ds.X), ptr(ds.Xt), ptr(ds.Y), ptr(ds.Psi), ptr(ds.OK), ptr(ds.llpart), ds.elem0, int(ds.int8),
+                                    ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)), ptr(ov))
+        i8 = self._i8_scratch
+        if self.profile and self._times is None:
+            self._times = _lib.StageTimes()
+        n_act = int(a.sum(axis=1).max()) if a.size else 0
+        sw = _lib.Sweep(N, B, self.n0, nloc, self.nb, self.obs, self.xi, int(self.visit_order), self.planes, i8[2] if i8 else 0,
+                        dsets, len(self.datasets), ptr(self.a_dev), ptr(self.W_dev), ptr(self.b_dev),
+                        ptr(dev["rho"]), ptr(dev["Jw"]), ptr(dev["hw"]), ptr(dev["label"]), ptr(dev["Jb"]), ptr(dev["hb"]), ptr(dev["c0"]),
+                        ptr(dev["perm"]), ptr(dev["u"]), ptr(dev["z"]), ptr(getattr(self, "inv_eta", None)), ptr(getattr(self, "G0", None)),
+                        ptr(self.ll), ptr(self.status), ptr(self.logodds),
+                        ptr(self.Wt), ptr(self.bias), ptr(self.border), ptr(self.skip), ptr(self._c0_dense),
+                        ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
+                        ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
+                        ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
+                        int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
+                        ctypes.pointer(self._times) if self.profile else None)
+        call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
+        if host_overlap is not None:
+            host_overlap()
+        # state, log-likelihood and flags back (waits for the stream)
+        a_i = np.empty((nloc, N), dtype=np.int32)
+        W_new = np.empty((nloc, N, B))
+        b_new = np.empty(nloc)
+        ll = np.empty(nloc)
+        status = np.empty(nloc, dtype=np.int32)
+        call("pgl_get_state", ctypes.byref(sw), a_i.ctypes.data, W_new.ctypes.data, b_new.ctypes.data, ll.ctypes.data, status.ctypes.data, st)
+        del keep
         if status.any():
             bad = np.nonzero(status)[0]
             raise np.linalg.LinAlgError("posterior system not positive definite for local neurons %s (flags %s)"
                                         % (bad[:8].tolist(), status[bad[:8]].tolist()))
-        a_new = self.a_dev.cpu().numpy().astype(bool)
-        W_new = self.W_dev.cpu().numpy().reshape(nloc, N, B).copy()
-        b_new = self.b_dev.cpu().numpy().copy()
-        return a_new, W_new, b_new, ll_before
+        return a_i.astype(bool), W_new, b_new, self._ll_host_np(ll)
 
     def _gram(self, s, nbb, slot):
-        """omega-weighted Gram of local neurons [s, s+nbb) into J slot `slot` (regression.py:251-252)"""
+        """omega-weighted Gram of local neurons [s, s+nbb) into the batch's J (regression.py:251-252): the stage on its own (probes, tests;
+        a sweep runs the same kernels from pgl_sweep)"""
         D, ldn, Dp, ldj = self.D, self.ldn, self.Dp, self.ldj
         st = self._st()
         J = self.Jslots[slot]
         if self.obs == 2:
-            h = self._tic("gram_scale", 8.0 * nbb * D * (D + 1) / 2)
             call("pgl_scaled_gram", ptr(self.G0), ldj, ctypes.c_void_p(self.inv_eta.data_ptr() + 8 * s), ptr(J), ldj, ldj * ldj, D, nbb, st)
-            self._toc(h)
             return
         for i, ds in enumerate(self.datasets):
             if ds.int8:
-                self._gram_int8(i, ds, s, nbb, J)
+                G = self._i8_scratch[2]
+                for g0 in range(0, nbb, G):
+                    gz = min(G, nbb - g0)
+                    self._i8_group(ds, ctypes.c_void_p(ds.OK.data_ptr() + 8 * (s + g0)), 2 * self.ldn, gz,
+                                   ctypes.c_void_p(J.data_ptr() + 8 * g0 * self.ldj * self.ldj), int(i > 0))
                 continue
-            h = self._tic("gram", float(nbb) * ds.T * D * (D + 1))     # algorithmic flops: lower triangle, 2 flop per MAC
             call("pgl_weighted_gram", ptr(ds.X), Dp, Dp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * s), 2 * ldn, ds.Tp, D, nbb, ptr(J), ldj,
                  ldj * ldj, int(i > 0), st)
-            self._toc(h)
-
-    def _gram_int8(self, i, ds, s, nbb, J):
-        """the same Gram through pgl_i8_* in groups of G neurons (the residue planes of omega_n X are `planes` T D bytes per neuron)"""
-        D, ldn, Dp, ldj = self.D, self.ldn, self.Dp, self.ldj
-        st = self._st()
-        G = self._i8_scratch[2]
-        for g0 in range(0, nbb, G):
-            gz = min(G, nbb - g0)
-            self._i8_group(ds, ctypes.c_void_p(ds.OK.data_ptr() + 8 * (s + g0)), 2 * self.ldn, gz,
-                           ctypes.c_void_p(J.data_ptr() + 8 * g0 * self.ldj * self.ldj), int(i > 0))
 
     def _i8_group(self, ds, om, ldo, gz, Jp, accumulate):
         """J[g] (+)= X' diag(om[:, g]) X for gz <= group size weight columns at `om` (device pointer, leading dimension ldo): column
@@ -497,91 +513,11 @@ class GibbsEngine(object):
         _, _, G, PB, R, stat = self._i8_scratch
         assert gz <= G
         npl = self.planes
-        h = self._tic("gram.stats", 8.0 * ds.T * D)
         call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
-        self._toc(h)
-        h = self._tic("gram.planes", float(npl) * gz * ds.T * D)        # bytes stored
         call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
-        self._toc(h)
-        h = self._tic("gram.int8", float(gz) * ds.T * D * (D + 1))
         call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)
-        self._toc(h)
-        h = self._tic("gram.crt", float(npl) * gz * D * (D + 1) / 2)
         call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), Jp, ldj, ldj * ldj, ds.T, D, gz, npl, accumulate, st)
-        self._toc(h)
-
-    def _post(self, s, nbb, slot, a_host, det, dev, skip):
-        """posterior assembly, collapsed flips and weight draw of local neurons [s, s+nbb) from J slot `slot`"""
-        N, B, D, ldn, Dp, ldj, kmax = self.N, self.B, self.D, self.ldn, self.Dp, self.ldj, self.kmax
-        strideJ = ldj * ldj
-        st = self._st()
-        Jb_ = self.Jslots[slot]
-        self.Jbuf = Jb_
-        off8 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 8 * int(elems))
-        off4 = lambda t, elems: ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
-        # ---- posterior assembly (regression.py:210-223, 253-260, 270-271)
-        if dev["label"] is None:
-            jw_p, hw_p, lab_p = off8(dev["Jw"], s * N * B * B), off8(dev["hw"], s * N * B), None
-        else:
-            jw_p, hw_p, lab_p = ptr(dev["Jw"]), ptr(dev["hw"]), off4(dev["label"], s * N)
-        call("pgl_assemble_posterior", ptr(self.Jbuf), ldj, strideJ, off8(self.border, s * Dp), off8(self.border, (ldn + s) * Dp), Dp,
-             jw_p, hw_p, lab_p, off8(dev["Jb"], s), off8(dev["hb"], s), nbb, N, B, st)
-        # ---- collapsed flips (regression.py:282-320)
-        hf = self._tic("flips")
-        if not det[s:s + nbb].all():
-            vo = int(self.visit_order)
-            fs = FlipState(ptr(self.Mtab), ldj, strideJ, nbb, N, B, off4(dev["perm"], s * N), off8(dev["u"], s * N), off8(dev["rho"], s * N),
-                           off8(dev["c0"], s * N), off4(self.a_dev, s * N), off4(skip, s), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt),
-                           ptr(self.batch_k), ptr(self.G), ptr(self.Lws), ptr(self.Ut), ptr(self.Wt_ws), ldj, off4(self.status, s), vo,
-                           off8(self.logodds, s * N) if self.logodds is not None else None)
-            if vo:
-                call("pgl_flip_visit_order", ctypes.byref(fs), ptr(self.Jbuf), ldj, strideJ, st)
-            else:
-                self.Mtab[:nbb].copy_(self.Jbuf[:nbb])
-            # initial sweep on S0 = {bias} U {active blocks}, in chunks of kmax pivots (rows named by position in visit order)
-            lists = []
-            for i in range(nbb):
-                if det[s + i]:
-                    lists.append(np.zeros(0, dtype=np.int32))
-                else:
-                    act = a_host[s + i]
-                    blocks = np.nonzero(act[dev["perm_host"][s + i]])[0] if vo else np.nonzero(act)[0]
-                    rows = (blocks[:, None] * B + np.arange(B)[None, :]).ravel()
-                    lists.append(np.concatenate(([D], rows)).astype(np.int32))
-            ck = 256                                     # pivots per initial chunk (pgl_flip_apply_chunk: 2 x 2 blocks of 128)
-            nchunk = max((len(l) + ck - 1) // ck for l in lists)
-            for c in range(nchunk):
-                idx = np.zeros((self.nb, kmax), dtype=np.int32)
-                cnt = np.zeros(self.nb, dtype=np.int32)
-                for i, l in enumerate(lists):
-                    part = l[c * ck:(c + 1) * ck]
-                    idx[i, :len(part)] = part
-                    cnt[i] = len(part)
-                self.d_idx.copy_(torch.from_numpy(idx))
-                self.d_cnt.copy_(torch.from_numpy(cnt))
-                self.d_sign.fill_(1.0)
-                h2 = self._tic("flips.init")
-                call("pgl_flip_apply_chunk", ctypes.byref(fs), int(cnt.max()), st)
-                self._toc(h2)
-            nwin = (N + self.R - 1) // self.R
-            for w in range(nwin):
-                h2 = self._tic("flips.decide")
-                call("pgl_flip_decide", ctypes.byref(fs), w, st)
-                self._toc(h2)
-                h2 = self._tic("flips.apply")
-                call("pgl_flip_apply_window", ctypes.byref(fs), w, st)
-                self._toc(h2)
-        self._toc(hf)
-        hc_ = self._tic("weights")
-        # ---- weights (regression.py:323-340)
-        cs = CholState(ptr(self.Jbuf), ldj, strideJ, off4(self.a_dev, s * N), ptr(self.act), D + 1, ptr(self.na), ptr(self.Ac), ldj, strideJ,
-                       ptr(self.hc), ptr(self.Tinv), off8(dev["z"], s * (D + 1)), D + 1, off8(self.W_dev, s * D), off8(self.b_dev, s), nbb, N, B,
-                       off4(self.status, s))
-        call("pgl_active_index", ctypes.byref(cs), st)
-        na_max = int(self.na[:nbb].max().item())
-        call("pgl_sample_weights", ctypes.byref(cs), na_max, st)
-        self._toc(hc_)
 
     # test hooks --------------------------------------------------------------------------------------------------
     @_on_device

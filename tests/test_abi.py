@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(lib, s), "libpyglm_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == declared_symbols()      # the ctypes table mirrors the header 1:1
-    assert _lib.load().pgl_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().pgl_abi_version() == _lib.ABI_VERSION == 3
     assert _lib.load().pgl_flip_kmax() == 320 and _lib.load().pgl_flip_window_blocks(5) == 64
     # host-side constants of the integer Gram: bits of the column norms per number of moduli, fewest moduli at the fp64 level
     lib = _lib.load()
@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_field_order():
     from pyglm_amd import _lib
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pyglm_hip.h")).read(), flags=re.S)
-    for cname, cls in [("pgl_flip_t", _lib.FlipState), ("pgl_chol_t", _lib.CholState)]:
+    for cname, cls in [("pgl_flip_t", _lib.FlipState), ("pgl_chol_t", _lib.CholState), ("pgl_dataset_t", _lib.Dataset), ("pgl_sweep_t", _lib.Sweep),
+                       ("pgl_stage_times_t", _lib.StageTimes)]:
         body = re.search(r"typedef struct \{([^{}]*)\} %s;" % cname, text).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -47,7 +48,7 @@ def test_struct_layouts_match_header_field_order():
             if not decl:
                 continue
             for part in decl.split(","):
-                names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+                names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", re.sub(r"\[[^\]]*\]", "", part).strip())[0])
         assert names == [f[0] for f in cls._fields_], (cname, names)
 
 
