@@ -34,7 +34,8 @@ const char* pgl_last_error(void);
 /* out[4*i..4*i+3] = Philox4x32-10(counter = (j | purpose<<24, elem0+i, stream lo, stream hi), key = seed). Test hook. */
 int pgl_philox_words(uint64_t seed, uint32_t purpose, uint32_t j, uint64_t elem0, uint64_t stream, uint32_t* out, size_t n, void* hip_stream);
 
-/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; b must be integer valued).
+/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; any real b >= 0: floor(b) <= 12 Devroye draws of PG(1, z) plus the sum-of-gammas series for
+ * the fractional part, the series alone for b > 12 -- pgl_rng.h).
  * Replaces pypolyagamma.pgdrawvpar(ppgs, n, z, out) at pyglm/regression.py:504-507 (samplers built at :474-477). */
 int pgl_pg_draw(const double* b, const double* z, double* out, size_t len, uint64_t seed, uint64_t stream, uint64_t elem0, void* hip_stream);
 

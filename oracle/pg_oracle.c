@@ -171,7 +171,58 @@ static double pg_draw_one(double z, pg_rng* r) {
     }
 }
 
-/* out[i] ~ PG(b[i], z[i]); b must be a non-negative integer valued double (Bernoulli: 1).
+/* ------------------------------------------------------------------ PG(b, z) for real b > 0
+ * Sum-of-gammas representation (Polson, Scott & Windle 2013, eq. 2):
+ *     omega = 1/(2 pi^2) sum_{k>=1} g_k / ((k - 1/2)^2 + z^2/(4 pi^2)),   g_k ~ Gamma(b, 1) i.i.d.
+ * The first PG_SERIES_TERMS terms are drawn; the remainder R = sum_{k>K} g_k / d_k is replaced by one gamma variate with R's exact mean
+ * b sum 1/d_k and variance b sum 1/d_k^2 (here the two sums are taken term by term up to k = K + 4000 and closed by their integrals --
+ * deliberately NOT the closed forms the device code uses).  Gamma variates: Marsaglia & Tsang (2000), "A simple method for
+ * generating gamma variables", ACM TOMS 26, without the squeeze; shape < 1 by the U^(1/shape) boost.
+ * PG(b, z) = floor(b) draws of PG(1, z) + PG(frac(b), z) by infinite divisibility; for b > PG_DEVROYE_MAX the whole shape goes through
+ * the series (cost independent of b). */
+#define PG_SERIES_TERMS 32
+#define PG_DEVROYE_MAX 12
+
+static double rng_gamma(double alpha, pg_rng* r) {
+    double boost = 1.0;
+    if (alpha < 1.0) { boost = exp(log(rng_unif(r)) / alpha); alpha += 1.0; }
+    const double d = alpha - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x, v;
+        do { x = rng_norm(r); v = 1.0 + c * x; } while (v <= 0.0);
+        v = v * v * v;
+        if (log(rng_unif(r)) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
+    }
+}
+
+static void pg_tail_sums(double c, double* S1, double* S2) {
+    const int K = PG_SERIES_TERMS, K2 = PG_SERIES_TERMS + 4000;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = K2; k > K; --k) {                       /* small terms first */
+        const double d = (k - 0.5) * (k - 0.5) + c;
+        s1 += 1.0 / d;
+        s2 += 1.0 / (d * d);
+    }
+    /* beyond K2: int_{K2}^inf dx/(x^2+c) and int dx/(x^2+c)^2 (midpoint rule; the neglected correction is O(K2^-3) of a 1e-4 share) */
+    const double x = (double)K2, sc = sqrt(c);
+    const double i1 = sc > 0 ? atan(sc / x) / sc : 1.0 / x;
+    const double i2 = 1.0 / (3.0 * x * x * x) - 2.0 * c / (5.0 * x * x * x * x * x);
+    *S1 = s1 + i1;
+    *S2 = s2 + i2;
+}
+
+static double pg_series(double b, double z, pg_rng* r) {
+    const double c = z * z / (4.0 * PG_PI * PG_PI);
+    double s = 0.0;
+    for (int k = 1; k <= PG_SERIES_TERMS; ++k) s += rng_gamma(b, r) / ((k - 0.5) * (k - 0.5) + c);
+    double S1, S2;
+    pg_tail_sums(c, &S1, &S2);
+    const double m = b * S1, v = b * S2;
+    s += (v / m) * rng_gamma(m * m / v, r);
+    return s / (2.0 * PG_PI * PG_PI);
+}
+
+/* out[i] ~ PG(b[i], z[i]); b real, >= 0 (Bernoulli: 1; negative binomial: y + xi).
  * Stands where the reference calls pgdrawvpar (regression.py:504-507). returns 0, or -1 on bad b. */
 int oracle_pg_draw(const double* b, const double* z, double* out, size_t len,
                    uint64_t seed, uint64_t stream, uint64_t elem0) {
@@ -181,15 +232,19 @@ int oracle_pg_draw(const double* b, const double* z, double* out, size_t len,
 #endif
     for (ptrdiff_t i = 0; i < (ptrdiff_t)len; ++i) {
         const double bi = b ? b[i] : 1.0;
-        if (!(bi >= 0) || bi != floor(bi) || bi > 1e6) { bad = 1; out[i] = NAN; continue; }
+        if (!(bi >= 0) || bi > 1e9) { bad = 1; out[i] = NAN; continue; }
         pg_rng r;
         r.key[0] = (uint32_t)seed; r.key[1] = (uint32_t)(seed >> 32);
         r.elem = (uint32_t)(elem0 + (uint64_t)i);
         r.s_lo = (uint32_t)stream; r.s_hi = (uint32_t)(stream >> 32);
         r.j = 0; r.purpose = PG_PURPOSE_PG; r.have = 0;
         double s = 0.0;
-        const long nb = (long)bi;
-        for (long k = 0; k < nb; ++k) s += pg_draw_one(z[i], &r);
+        if (bi > (double)PG_DEVROYE_MAX) s = pg_series(bi, z[i], &r);
+        else if (bi > 0.0) {
+            const double fl = floor(bi), frac = bi - fl;
+            for (int k = 0; k < (int)fl; ++k) s += pg_draw_one(z[i], &r);
+            if (frac > 0.0) s += pg_series(frac, z[i], &r);
+        }
         out[i] = s;
     }
     return bad ? -1 : 0;

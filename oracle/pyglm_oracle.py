@@ -169,7 +169,7 @@ def pg_draw(b, z, seed, stream, elem0=0):
         bp = b.ctypes.data
     rc = lib.oracle_pg_draw(bp, z.ctypes.data, out.ctypes.data, z.size, seed, stream, elem0)
     if rc != 0:
-        raise ValueError("oracle_pg_draw: b must be a non-negative integer-valued array")
+        raise ValueError("oracle_pg_draw: b must be non-negative")
     return out
 
 

@@ -93,7 +93,7 @@ int pgl_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, 
                   double* llpart, double* ll_out, int accumulate, int T, int nloc, int obs, double xi, uint64_t seed, uint64_t sweep,
                   uint64_t neuron0, uint64_t elem0, void* st) {
     PGL_CHECK_ARG(Psi && Y && llpart && ll_out && T > 0 && nloc > 0 && (obs == 0 || obs == 1));
-    PGL_CHECK_ARG(obs == 0 || (xi > 0 && xi == (double)(long)xi));
+    PGL_CHECK_ARG(obs == 0 || xi > 0);
     return pgl_k_pg_loglik(Psi, ldpsi, bias, Y, ldy, Omega, ldo, Kappa, ldk, llpart, ll_out, accumulate, T, nloc, obs, xi, seed, sweep, neuron0,
                            elem0, ST(st));
 }

@@ -388,15 +388,22 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
             }
 }
 
-// persistent: one workgroup per CU.  The items (neuron of the group, plane, tile in clustered order) are cut into chunks of CH; chunk c
-// belongs to XCD c % 8; a workgroup reads the XCC it runs on and pulls the next item of that XCD's list, stealing from the next XCD when
-// its own list is exhausted.  Placement is used for speed only -- any placement gives the same result.
+// persistent: one workgroup per CU pulls (neuron of the group, plane, tile in clustered order) items from per-XCD work lists; a workgroup
+// reads the XCC it runs on and takes the next item of that XCD's list, stealing from the next XCD when its own list is exhausted.
+//   G == 8 (every full group): XCD y owns NEURON y -- its list is that neuron's (plane, tile) items in order.  The 32 workgroups of an
+//     XCD then walk one 6 x 6 super-block of one plane together (they share its ~12 strips through their L2), and the eight XCDs walk
+//     the SAME plane and super-block at the same time, each for its own neuron: the X-plane strips (half of every item's operand
+//     stream, identical for all neurons) are fetched from HBM once and found in the memory-side cache by the other seven.
+//   otherwise: the flat item list is cut into chunks of CH, chunk c belongs to XCD c % 8.
+// Placement is used for speed only -- any placement gives the same result.
 __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int* ticket = reinterpret_cast<int*>(lds + NST * STAGE_BYTES);
     const int ntm = g.Dq / TM;
     const int ntiles = ntm * (ntm + 1) / 2;
-    const int total = ntiles * g.np * g.G;
+    const int per_neuron = ntiles * g.np;
+    const int total = per_neuron * g.G;
+    const bool by_neuron = g.G == 8;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
@@ -407,8 +414,11 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
             for (int hop = 0; hop < 8 && w < 0; ++hop) {
                 const int y = (int)((xcc + hop) & 7u);
                 const int it = atomicAdd(&g.sched[y], 1);
-                const long cand = ((long)(it / CH) * 8 + y) * CH + it % CH;
-                if (cand < total) w = (int)cand;
+                if (by_neuron) { if (it < per_neuron) w = y * per_neuron + it; }
+                else {
+                    const long cand = ((long)(it / CH) * 8 + y) * CH + it % CH;
+                    if (cand < total) w = (int)cand;
+                }
             }
             if (w >= 0) {
                 int tm, tn;

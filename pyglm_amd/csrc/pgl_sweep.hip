@@ -124,7 +124,7 @@ int pgl_stage_times_collect(pgl_stage_times_t* t) {
 int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     PGL_CHECK_ARG(s && s->N > 0 && s->B > 0 && s->B <= 32 && s->nloc > 0 && s->nb > 0 && s->n0 >= 0 && s->ndatasets > 0 && s->datasets);
-    PGL_CHECK_ARG(s->obs >= 0 && s->obs <= 2 && (s->obs != 1 || (s->xi > 0 && s->xi == std::floor(s->xi))));
+    PGL_CHECK_ARG(s->obs >= 0 && s->obs <= 2 && (s->obs != 1 || s->xi > 0));
     PGL_CHECK_ARG(s->a && s->W && s->b && s->rho && s->Jw && s->hw && s->Jb && s->hb && s->c0 && s->perm && s->u && s->z && s->ll && s->status);
     PGL_CHECK_ARG(s->Wt && s->bias && s->border && s->skip && s->Jbuf && s->Mtab && s->Ac && s->hc && s->Tinv && s->G && s->Lws && s->Ut && s->Wt_ws);
     PGL_CHECK_ARG(s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->act && s->na && (s->label == nullptr || s->c0_dense != nullptr));

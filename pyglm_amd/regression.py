@@ -282,7 +282,7 @@ class SparseNegativeBinomialRegression(_SparsePGRegressionBase):
     _obs = "negbin"
 
     def __init__(self, N, B, xi=1.0, **kwargs):
-        assert xi > 0 and float(xi) == int(xi), "integer shape xi required (PG(b, z) is drawn as a sum of b PG(1, z))"
+        assert xi > 0
         self.xi = float(xi)
         super(SparseNegativeBinomialRegression, self).__init__(N, B, **kwargs)
 

@@ -64,6 +64,64 @@ def test_pg_draw_matches_oracle(torch_dev, zscale):
     assert np.all(got[b == 0] == 0)
 
 
+def _device_pg(b, z, n, seed, stream):
+    import torch
+    from pyglm_amd._lib import call, ptr
+    zd = torch.full((n,), float(z), dtype=torch.float64, device="cuda:0")
+    bd = torch.full((n,), float(b), dtype=torch.float64, device="cuda:0")
+    out = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, seed, stream, 0, None)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("b", [1.0, 2.0, 7.0, 50.0, 0.3, 2.5, 13.7])
+def test_device_pg_analytic_checks(torch_dev, b):
+    """the DEVICE sampler against known answers, not against its twin in the oracle: mean, variance and the Laplace transform
+    E exp(-t w) = (cosh(z/2) / cosh(sqrt((z^2/2 + t)/2)))^b over z in {0, 0.3, 2, 6, 20, 40}, integer and real shapes b"""
+    from tests.test_oracle_pg import pg_mean, pg_var, pg_laplace, Z_GRID
+    n = 300000
+    for iz, z in enumerate(Z_GRID):
+        om = _device_pg(b, z, n, 17, orc.stream_id(iz, int(b * 10)))
+        assert np.all(om > 0) and np.all(np.isfinite(om))
+        m, v = float(pg_mean(b, z)), float(pg_var(b, z))
+        assert abs(om.mean() - m) < 5 * np.sqrt(v / n), (b, z)
+        assert abs(om.var() - v) < 0.03 * v, (b, z)
+        for t in (0.5 / m, 2.0 / m):
+            g = np.exp(-t * om)
+            assert abs(g.mean() - pg_laplace(b, z, t)) < 5 * g.std() / np.sqrt(n), (b, z, t)
+
+
+@pytest.mark.parametrize("b,z", [(1.0, 0.0), (1.0, 6.0), (2.0, 0.3), (7.0, 2.0), (50.0, 20.0), (0.3, 0.0), (2.5, 2.0), (13.7, 40.0)])
+def test_device_pg_ks_against_gamma_series(torch_dev, b, z):
+    """Kolmogorov-Smirnov of device draws against the defining sum-of-gammas series (600 terms, NumPy)"""
+    from scipy import stats
+    from tests.test_oracle_pg import gamma_series_sample
+    n = 20000
+    ref = gamma_series_sample(b, z, n, np.random.default_rng(int(b * 100 + z)))
+    om = _device_pg(b, z, n, 5, orc.stream_id(1, 2))
+    assert stats.ks_2samp(om, ref).pvalue > 1e-3
+
+
+def test_device_pg_real_shapes_match_oracle(torch_dev):
+    """real-valued shapes on a shared stream: the series branch consumes the stream identically on both sides; the remainder's moments are
+    computed by different formulas (closed form on the device, term-by-term sums in the oracle), hence 1e-9 instead of 1e-12"""
+    torch = torch_dev
+    from pyglm_amd._lib import call, ptr
+    n = 60000
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal(n) * 4.0
+    b = np.where(rng.random(n) < 0.5, rng.random(n) * 3.0, rng.random(n) * 40.0)
+    b[:4] = [0.0, 1e-3, 12.0, 12.000001]
+    zd, bd = torch.from_numpy(z).cuda(), torch.from_numpy(b).cuda()
+    out = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, 9, orc.stream_id(2, 3), 5, None)
+    got = out.cpu().numpy()
+    want = orc.pg_draw(b, z, 9, orc.stream_id(2, 3), 5)
+    assert got[0] == 0.0 and np.all(np.isfinite(got)) and np.all(got[1:] > 0)
+    close = np.abs(got - want) <= 1e-9 * np.abs(want) + 1e-300
+    assert close.mean() >= 1 - 2e-3, "only %.6f of draws agree" % close.mean()
+
+
 def test_pg_moments_at_scale(torch_dev):
     torch = torch_dev
     from pyglm_amd._lib import call, ptr

@@ -89,4 +89,52 @@ def test_pg_integer_b_is_sum_and_streams_are_independent():
     np.testing.assert_array_equal(a[500:], d)            # element index, not call order, keys the draw
     assert orc.pg_draw(np.zeros(4), np.zeros(4), 1, 0).tolist() == [0, 0, 0, 0]   # PG(0, z) = 0
     with pytest.raises(ValueError):
-        orc.pg_draw(np.full(4, 0.5), np.zeros(4), 1, 0)
+        orc.pg_draw(np.full(4, -0.5), np.zeros(4), 1, 0)
+
+
+def pg_laplace(b, z, t):
+    """E exp(-t w) for w ~ PG(b, z): (cosh(z/2) / cosh(sqrt((z^2/2 + t)/2)))^b, in logs (cosh overflows at z = 40)"""
+    lc = lambda x: np.logaddexp(x, -x) - np.log(2.0)
+    return np.exp(b * (lc(z / 2) - lc(np.sqrt((z * z / 2 + t) / 2))))
+
+
+def gamma_series_sample(b, z, n, rng, K=600):
+    """reference sample of PG(b, z) from its defining series, K terms + the mean of the remainder (3e-5 of the mean)"""
+    k = np.arange(1, K + 1)
+    denom = (k - 0.5) ** 2 + z * z / (4 * np.pi ** 2)
+    out = np.empty(n)
+    for i0 in range(0, n, 2000):
+        m = min(2000, n - i0)
+        out[i0:i0 + m] = (rng.gamma(b, size=(m, K)) / denom).sum(1)
+    kk = np.arange(K + 1, 400000)
+    out += b * (1.0 / ((kk - 0.5) ** 2 + z * z / (4 * np.pi ** 2))).sum()
+    return out / (2 * np.pi ** 2)
+
+
+REAL_B = [0.3, 1.0, 2.0, 2.5, 7.0, 12.0, 13.7, 50.0]
+Z_GRID = [0.0, 0.3, 2.0, 6.0, 20.0, 40.0]
+
+
+@pytest.mark.parametrize("b", REAL_B)
+def test_pg_real_shape_moments_and_laplace(b):
+    """PG(b, z) for real-valued b (regression.py:479-489 hands real shapes to pgdrawvpar): mean, variance and the Laplace transform at
+    two arguments, over z from 0 to 40, for shapes on every branch (series only, Devroye only, Devroye + series, series for b > 12)"""
+    n = 120000
+    for iz, z in enumerate(Z_GRID):
+        om = orc.pg_draw(np.full(n, b), np.full(n, z), seed=31, stream=orc.stream_id(iz, int(b * 10)))
+        assert np.all(om > 0) and np.all(np.isfinite(om))
+        m, v = pg_mean(b, z), pg_var(b, z)
+        assert abs(om.mean() - m) < 5 * np.sqrt(v / n), (b, z)
+        assert abs(om.var() - v) < 0.04 * v, (b, z)
+        for t in (0.5 / m, 2.0 / m):                     # arguments on the scale of the distribution
+            g = np.exp(-t * om)
+            assert abs(g.mean() - pg_laplace(b, z, t)) < 5 * g.std() / np.sqrt(n), (b, z, t)
+
+
+@pytest.mark.parametrize("b,z", [(0.3, 0.0), (0.3, 6.0), (2.5, 2.0), (13.7, 0.3), (50.0, 20.0)])
+def test_pg_real_shape_ks_against_gamma_series(b, z):
+    rng = np.random.default_rng(int(b * 100 + z))
+    n = 20000
+    ref = gamma_series_sample(b, z, n, rng)
+    om = orc.pg_draw(np.full(n, b), np.full(n, z), seed=77, stream=orc.stream_id(2, 5))
+    assert stats.ks_2samp(om, ref).pvalue > 1e-3
