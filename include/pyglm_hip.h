@@ -91,27 +91,30 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
 
 /* ---- the same weighted Gram on the INTEGER matrix cores -------------------------------------------
  * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to integers
- *     A[t][i] = rint(x_ti sA_i),   B_g[t][j] = rint((omega_gt x_tj) sB_gj),      sA, sB powers of two,
+ *     A[t][i] = rint(x_ti sA_i),   B_g[t][j] = rint((omega_gt x_tj) sB_gj),
  * one int8 GEMM per modulus for the first `nplanes` of 15 pairwise coprime moduli <= 256 (256, 255, 253, 251, 247, 241, 239, 233, 229,
  * 227, 223, 217, 211, 199, 197), int32 accumulation (re-reduced every 128 000 bins), exact Chinese-remainder reconstruction,
- * J_ij = S_ij / (sA_i sB_gj).  The scales are set from each column's Euclidean norm and largest element so that the integer columns have
- * norms in [2^(nu-1), 2^nu) (nu = pgl_i8_norm_bits(nplanes, T): 50 / 54 / 58 for 13 / 14 / 15 moduli) unless their largest element would
- * reach 2^50; Cauchy-Schwarz then keeps every |S_ij| inside the CRT range for any data, and the rounding error of J_ij has standard
- * deviation sqrt((|A_i|^-2 + |B_gj|^-2) / 12) |a_i||b_gj| (<= 7.3e-16 |a_i||b_gj| at 13 moduli): pinned to the column norms.
+ * J_ij = (S_ij / sA_i) / sB_gj.  The scales are set from each column's Euclidean norm and largest element so that the integer columns have
+ * norm pgl_i8_norm_limit(nplanes, T) (2^46.9 / 2^50.8 / 2^54.6 / 2^58.4 for 12 / 13 / 14 / 15 moduli; pgl_i8_norm_bits = floor(log2)) unless
+ * their largest element would reach 2^50; Cauchy-Schwarz then keeps every |S_ij| inside the CRT range for any data, and the rounding
+ * error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_gj|^-2) / 12) |a_i||b_gj| (2.1e-16 |a_i||b_gj| at 13 moduli): pinned to the
+ * column norms.
  *   pgl_i8_colstats amax[g][c] = max_t |v_tc|, sumsq[g][c] = sum_t v_tc^2 with v = X (Om = NULL, G = 1) or Om[:, g] * X, G <= 8; one pass
  *                   over X, deterministic (fixed summation order)
  *   pgl_i8_scales   scale[k] from (amax[k], sumsq[k]) for ncols = G * D columns (1 for an empty column, NaN for a non-finite one)
- *   pgl_i8_planes   residue planes [G][nplanes] of Dq * Kp signed bytes each (Dq = D rounded up to 256, Kp = T rounded up to 64, at least
- *                   256), BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024
+ *   pgl_i8_planes   residue planes [G][nplanes] of Dq * Kp signed bytes each (Dq = pgl_i8_padded_rows(D): D rounded up to the product
+ *                   kernel's tile edge, 320 -- or 256 with PGL_I8_TILE=256 in the environment; Kp = T rounded up to 64, at least 256), BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024
  *                   + (r % 16) 64; of X (Om = NULL, G = 1) or of omega_g X for the G columns of Om; scale [G][D]; buffer sizes from
  *                   pgl_i8_plane_bytes (per neuron, at the full 15 planes)
- *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower 256 x 256 tiles, [G][nplanes][Dq][Dq] signed bytes
+ *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower-triangular tiles, [G][nplanes][Dq][Dq] signed bytes
  *                   (buffer: G * pgl_i8_residue_bytes(D))
  *   pgl_i8_crt      J[g] (+)= X' diag(omega_g) X, lower triangle, from the residues (scale_x [D], scale_wx [G][D])
  * The same nplanes must be used for the scales, both plane sets, the product and the reconstruction. */
 int pgl_i8_max_planes(void);                     /* 15 */
+int pgl_i8_padded_rows(int D);                   /* Dq */
 int pgl_i8_min_planes(int T);                    /* fewest moduli with norm bits >= 50 (error at the fp64 product's level): 13 */
-int pgl_i8_norm_bits(int nplanes, int T);        /* nu(nplanes, T) */
+int pgl_i8_norm_bits(int nplanes, int T);        /* floor(log2(pgl_i8_norm_limit)) */
+double pgl_i8_norm_limit(int nplanes, int T);    /* norm of the integer columns */
 size_t pgl_i8_plane_bytes(int D, int T);
 size_t pgl_i8_residue_bytes(int D);
 int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* hip_stream);
@@ -145,11 +148,12 @@ typedef struct {
                                           * formed at pyglm/regression.py:293-307 -- the change in log marginal likelihood (:343-378)
                                           * plus log rho - log(1 - rho); NaN where rho is exactly 0 or 1 (the reference's 0 log 0) */
 } pgl_flip_t;
-int pgl_flip_kmax(void);                         /* pivots (scalar rows) per tableau update */
+int pgl_flip_kmax(void);                         /* max pivots (scalar rows) per tableau update: 512 */
 int pgl_flip_window_blocks(int B);               /* blocks proposed per window */
 int pgl_flip_apply(const pgl_flip_t* s, void* hip_stream);              /* sweep the tableau on the listed pivots (<= 128 per call is fast) */
-/* same for lists of up to max_pivots <= 256 rows per neuron that are all switched ON (the pivot block is positive definite): the
- * initial sweep on the active set; the 256 x 256 pivot-block inverse is assembled from two in-LDS 128 x 128 inversions. Uses Lws. */
+/* same for lists of up to max_pivots <= pgl_flip_kmax() = 512 rows per neuron that are all switched ON (the pivot block is positive
+ * definite): the initial sweep on the active set; the pivot-block inverse is assembled by recursive 2 x 2 blocking from in-register
+ * 128 x 128 inversions. Uses Lws. */
 int pgl_flip_apply_chunk(const pgl_flip_t* s, int max_pivots, void* hip_stream);
 /* same, right after pgl_flip_decide(window) (which already left G = (M_DD)^-1); with visit_order = 1 only the trailing square from
  * position (window+1)*R on is updated -- rows of proposed blocks are never read again (nothing at all after the last window) */

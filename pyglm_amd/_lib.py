@@ -63,8 +63,10 @@ SIGNATURES = {
     "pgl_i8_plane_bytes": [c_i, c_i],
     "pgl_i8_residue_bytes": [c_i],
     "pgl_i8_max_planes": [],
+    "pgl_i8_padded_rows": [c_i],
     "pgl_i8_min_planes": [c_i],
     "pgl_i8_norm_bits": [c_i, c_i],
+    "pgl_i8_norm_limit": [c_i, c_i],
     "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
     "pgl_i8_scales": [c_p, c_p, c_l, c_i, c_i, c_p, c_p],
     "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -104,12 +106,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PglError("libpyglm_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "or `make -C pyglm_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    import torch  # noqa: F401  -- FIRST: PyTorch-ROCm carries its own HIP runtime; a process must bind one runtime only, and the library's
+    #                      dependency on libamdhip64 has to resolve to the copy torch has loaded (loading the library first leaves
+    #                      two runtimes in the process: "no ROCm-capable device is detected" at the first launch)
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the export is missing
         fn.argtypes = args
         fn.restype = (ctypes.c_char_p if name in ("pgl_last_error", "pgl_stage_name") else ctypes.c_size_t if name in ("pgl_i8_plane_bytes", "pgl_i8_residue_bytes")
-                      else ctypes.c_int)
+                      else ctypes.c_double if name == "pgl_i8_norm_limit" else ctypes.c_int)
     if lib.pgl_abi_version() != ABI_VERSION:
         raise PglError("libpyglm_hip.so ABI version %d != %d (rebuild: make -C pyglm_amd/csrc)" % (lib.pgl_abi_version(), ABI_VERSION))
     _lib = lib

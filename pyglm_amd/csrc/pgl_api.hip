@@ -146,8 +146,10 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
 size_t pgl_i8_plane_bytes(int D, int T) { return pgl_k_i8_plane_bytes(D, T); }
 size_t pgl_i8_residue_bytes(int D) { return pgl_k_i8_residue_bytes(D); }
 int pgl_i8_max_planes(void) { return pgl_k_i8_max_planes(); }
+int pgl_i8_padded_rows(int D) { return pgl_k_i8_padded_rows(D); }
 int pgl_i8_min_planes(int T) { return pgl_k_i8_min_planes(T); }
 int pgl_i8_norm_bits(int nplanes, int T) { return pgl_k_i8_nu(nplanes, T); }
+double pgl_i8_norm_limit(int nplanes, int T) { return pgl_k_i8_norm_limit(nplanes, T); }
 #define PGL_CHECK_PLANES(np, T) PGL_CHECK_ARG((np) >= 1 && (np) <= pgl_k_i8_max_planes() && pgl_k_i8_nu((np), (T)) >= 8)
 int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* st) {
     PGL_CHECK_ARG(X && amax && sumsq && T > 0 && D > 0 && G >= 1 && G <= 8 && ldx >= D && (Om == nullptr ? G == 1 : ldo >= G));

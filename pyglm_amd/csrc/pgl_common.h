@@ -97,8 +97,10 @@ int pgl_k_assemble_post(double*, long, long, const double*, const double*, long,
 size_t pgl_k_i8_plane_bytes(int, int);
 size_t pgl_k_i8_residue_bytes(int);
 int pgl_k_i8_max_planes(void);
+int pgl_k_i8_padded_rows(int);
 int pgl_k_i8_min_planes(int);
 int pgl_k_i8_nu(int, int);
+double pgl_k_i8_norm_limit(int, int);
 int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
 int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
 int pgl_k_i8_planes(const double*, long, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);

@@ -23,8 +23,8 @@
 
 namespace {
 
-constexpr int KMAX = 320;   // max pivots (scalar rows) per tableau update = max scalar rows of the blocks of one proposal window
-constexpr int KWIN = KMAX;  // the window's sub-tableau and the pivot-block inverse live in an L2-resident global scratch, not in LDS
+constexpr int KMAX = 512;   // max pivots (scalar rows) per tableau update: a chunk of the initial sweep (rank-512 passes over the tableau)
+constexpr int KWIN = 320;   // max scalar rows of the blocks of one proposal window (its sub-tableau lives in an L2-resident global scratch)
 
 struct FlipArgs {
     double* M; long ldj; long strideM;           // tableau per neuron
@@ -283,17 +283,17 @@ __global__ __launch_bounds__(256) void invert_kernel(FlipArgs g) {
 // 128^3 products on the MFMA kernel)   with T = G_A M_AB, S = M_BB - M_BA T:
 //     G_BB = S^-1,   G_BA = -S^-1 T',   G_AA = G_A + T S^-1 T' = G_A - G_BA' T'
 constexpr int KB2 = 128;            // block size
-// Akk[i][j] = M[idx[i]][idx[j]] for i, j < k, identity elsewhere in the 256 x 256 frame (so the fixed-size block products and
+// Akk[i][j] = M[idx[i]][idx[j]] for i, j < k, identity elsewhere in the frame x frame corner (so the fixed-size block products and
 // inversions need no per-neuron sizes)
-__global__ __launch_bounds__(256) void gather_kk_kernel(FlipArgs g) {
+__global__ __launch_bounds__(256) void gather_kk_kernel(FlipArgs g, int frame) {
     const int n = blockIdx.y, tid = threadIdx.x;
     const int k = g.d_cnt[n];
     double* A = g.Lws + (size_t)n * KMAX * KMAX;
     const double* M = g.M + (long)n * g.strideM;
     const int* idx = g.d_idx + (long)n * KMAX;
     const int e = blockIdx.x * 256 + tid;
-    if (e >= 2 * KB2 * 2 * KB2) return;
-    const int i = e / (2 * KB2), j = e % (2 * KB2);
+    if (e >= frame * frame) return;
+    const int i = e / frame, j = e % frame;
     double v = (i == j) ? 1.0 : 0.0;
     if (i < k && j < k) v = tab_get(M, g.ldj, idx[i], idx[j]);
     A[i * KMAX + j] = v;
@@ -352,23 +352,30 @@ __global__ __launch_bounds__(256) void invert128_kernel(FlipArgs g, const double
     if (tid == 0 && s_bad) atomicOr(&g.status[n], 2);
 }
 
-// off-diagonal blocks from the scratch frame, zeros outside the k x k corner, padded K for the panel products
-__global__ __launch_bounds__(256) void finalize_g_kernel(FlipArgs g) {
+// one level of the block inverse is done: G's off-diagonal blocks of the 2h x 2h square at offset o come from the scratch frame
+// (G_BA = Akk[BA], G_AB = G_BA')
+__global__ __launch_bounds__(256) void offdiag_g_kernel(FlipArgs g, int o, int h) {
+    const int n = blockIdx.y;
+    double* Gn = g.G + (size_t)n * KMAX * KMAX;
+    const double* A = g.Lws + (size_t)n * KMAX * KMAX;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= h * h) return;
+    const int i = e / h, j = e % h;                          // element (i, j) of the BA block
+    const double v = A[(o + h + i) * KMAX + o + j];
+    Gn[(o + h + i) * KMAX + o + j] = v;
+    Gn[(o + j) * KMAX + o + h + i] = v;
+}
+
+// zeros outside the k x k corner (the frame holds the identity there), padded K for the panel products
+__global__ __launch_bounds__(256) void mask_g_kernel(FlipArgs g) {
     const int n = blockIdx.y, tid = threadIdx.x;
     const int k = g.d_cnt[n];
     double* Gn = g.G + (size_t)n * KMAX * KMAX;
-    const double* A = g.Lws + (size_t)n * KMAX * KMAX;
     const int e = blockIdx.x * 256 + tid;
     if (e == 0) g.batch_k[n] = (k + 15) & ~15;
     if (e >= KMAX * KMAX) return;
     const int i = e / KMAX, j = e % KMAX;
-    double v = 0.0;
-    if (i < k && j < k) {
-        if (i >= KB2 && j < KB2) v = A[i * KMAX + j];                 // G_BA
-        else if (i < KB2 && j >= KB2) v = A[j * KMAX + i];            // G_AB = G_BA'
-        else v = Gn[e];
-    }
-    Gn[e] = v;
+    if (i >= k || j >= k) Gn[e] = 0.0;
 }
 
 // ------------------------------------------------------------------ Ut[q][c] = M[idx[q], c]  (old panel, k-major), zero rows up to the padded K
@@ -604,31 +611,47 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
     if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(invert_kernel), lds_inv, once)) return rc;
     const int Md = Md_;
     if (!have_G && max_pivots > KB2) {
-        if (max_pivots > 2 * KB2) { pgl_set_error("flip_apply: %d pivots per call (max %d)", max_pivots, 2 * KB2); return PGL_ERR_ARG; }
-        const size_t lds128 = 0;
+        if (max_pivots > KMAX) { pgl_set_error("flip_apply: %d pivots per call (max %d)", max_pivots, KMAX); return PGL_ERR_ARG; }
+        // G = (M_PP)^-1 on a frame of 256 or 512 rows (identity beyond a neuron's own pivots), by recursive 2 x 2 blocking down to the
+        // in-register 128 x 128 inversion:  T = G_A M_AB,  S = M_BB - M_BA T,  G_BB = S^-1,  G_BA = -S^-1 T',  G_AA = G_A - G_BA' T'
+        const int frame = max_pivots > 2 * KB2 ? 4 * KB2 : 2 * KB2;
         const long sq = (long)KMAX * KMAX;
         double* Akk = s.Lws;
-        hipLaunchKernelGGL(gather_kk_kernel, dim3(2 * KB2 * 2 * KB2 / 256, s.nb), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gather_kk_kernel, dim3(frame * frame / 256, s.nb), dim3(256), 0, st, g, frame);
         PGL_CHECK_LAUNCH();
-        hipLaunchKernelGGL(invert128_kernel, dim3(s.nb), dim3(256), lds128, st, g, (const double*)Akk, s.G, 0);
-        PGL_CHECK_LAUNCH();
-        auto block_gemm = [&](const double* A, const double* Bm, double* C, double alpha, double beta) {
+        auto block_gemm = [&](const double* A, const double* Bm, double* C, double alpha, double beta, int h) {
             PglGemmArgs q{};
             q.A = A; q.lda = KMAX; q.strideA = sq; q.B = Bm; q.ldb = KMAX; q.strideB = sq; q.C = C; q.ldc = KMAX; q.strideC = sq;
-            q.M = KB2; q.N = KB2; q.K = KB2; q.a_cols = KB2; q.b_cols = KB2; q.nbatch = s.nb; q.alpha = alpha; q.beta = beta; q.tri = 0;
+            q.M = h; q.N = h; q.K = h; q.a_cols = h; q.b_cols = h; q.nbatch = s.nb; q.alpha = alpha; q.beta = beta; q.tri = 0;
             return pgl_launch_gemm(PGL_GEMM_PLAIN, q, st);
         };
-        double* G_AA = s.G;                 double* T = s.G + KB2;                    // T  (A x B) in G's upper-right block
-        double* Tt = s.G + (long)KB2 * KMAX; double* G_BB = s.G + (long)KB2 * KMAX + KB2;
-        const double* M_AB = Akk + KB2;     double* S = Akk + (long)KB2 * KMAX + KB2; double* G_BA = Akk + (long)KB2 * KMAX;
-        int rc = block_gemm(G_AA, M_AB, T, 1.0, 0.0);            if (rc) return rc;   // T  = G_A M_AB
-        rc = block_gemm(M_AB, G_AA, Tt, 1.0, 0.0);               if (rc) return rc;   // T' = M_BA G_A
-        rc = block_gemm(M_AB, T, S, -1.0, 1.0);                  if (rc) return rc;   // S  = M_BB - M_BA T
-        hipLaunchKernelGGL(invert128_kernel, dim3(s.nb), dim3(256), lds128, st, g, (const double*)Akk, s.G, KB2);   // G_BB = S^-1
-        PGL_CHECK_LAUNCH();
-        rc = block_gemm(G_BB, Tt, G_BA, -1.0, 0.0);              if (rc) return rc;   // G_BA = -S^-1 T'
-        rc = block_gemm(G_BA, Tt, G_AA, -1.0, 1.0);              if (rc) return rc;   // G_AA = G_A - G_BA' T'
-        hipLaunchKernelGGL(finalize_g_kernel, dim3((KMAX * KMAX + 255) / 256, s.nb), dim3(256), 0, st, g);
+        struct Rec {
+            static int inv(const decltype(block_gemm)& gemm, const PglFlipState& s, const FlipArgs& g, double* Akk, int o, int n, hipStream_t st) {
+                if (n == KB2) {
+                    hipLaunchKernelGGL(invert128_kernel, dim3(s.nb), dim3(256), 0, st, g, (const double*)Akk, s.G, o);
+                    PGL_CHECK_LAUNCH();
+                    return PGL_OK;
+                }
+                const int h = n / 2;
+                int rc = inv(gemm, s, g, Akk, o, h, st);                                               if (rc) return rc;   // G_AA = M_AA^-1
+                double* G_AA = s.G + (long)o * KMAX + o;             double* T = s.G + (long)o * KMAX + o + h;              // T in G's upper-right block
+                double* Tt = s.G + (long)(o + h) * KMAX + o;         double* G_BB = s.G + (long)(o + h) * KMAX + o + h;
+                const double* M_AB = Akk + (long)o * KMAX + o + h;   double* S = Akk + (long)(o + h) * KMAX + o + h;
+                double* G_BA = Akk + (long)(o + h) * KMAX + o;
+                rc = gemm(G_AA, M_AB, T, 1.0, 0.0, h);                                                  if (rc) return rc;   // T  = G_A M_AB
+                rc = gemm(M_AB, G_AA, Tt, 1.0, 0.0, h);                                                 if (rc) return rc;   // T' = M_BA G_A
+                rc = gemm(M_AB, T, S, -1.0, 1.0, h);                                                    if (rc) return rc;   // S  = M_BB - M_BA T
+                rc = inv(gemm, s, g, Akk, o + h, h, st);                                                if (rc) return rc;   // G_BB = S^-1
+                rc = gemm(G_BB, Tt, G_BA, -1.0, 0.0, h);                                                if (rc) return rc;   // G_BA = -S^-1 T'
+                rc = gemm(G_BA, Tt, G_AA, -1.0, 1.0, h);                                                if (rc) return rc;   // G_AA = G_A - G_BA' T'
+                hipLaunchKernelGGL(offdiag_g_kernel, dim3((h * h + 255) / 256, s.nb), dim3(256), 0, st, g, o, h);
+                PGL_CHECK_LAUNCH();
+                return PGL_OK;
+            }
+        };
+        int rc = Rec::inv(block_gemm, s, g, Akk, 0, frame, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mask_g_kernel, dim3((KMAX * KMAX + 255) / 256, s.nb), dim3(256), 0, st, g);
         PGL_CHECK_LAUNCH();
     } else if (!have_G) {
         hipLaunchKernelGGL(invert_kernel, dim3(s.nb), dim3(256), lds_inv, st, g);

@@ -1,18 +1,18 @@
 // The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (the engine's choice at large shapes,
 // the fp64 kernel of pgl_gemm.hip otherwise).  The fp64 operands are scaled COLUMN BY COLUMN to integers,
 //     A[t][i] = rint(x_ti sA_i),      B_n[t][j] = rint((omega_nt x_tj) sB_nj),
-// with power-of-two scales chosen from each column's Euclidean norm and largest element (i8_colstats_kernel, i8_scales_kernel):
-//     |A_i|_2, |B_nj|_2 in [2^(nu-1), 2^nu)   unless the largest element would reach 2^50 (then that bound decides),
+// with scales chosen from each column's Euclidean norm and largest element (i8_colstats_kernel, i8_scales_kernel):
+//     |A_i|_2 = |B_nj|_2 = limit(K, T)   unless the largest element would reach 2^50 (then that bound decides),
 // so that by Cauchy-Schwarz every entry of the integer Gram S = A'B_n obeys |S_ij| <= |A_i||B_nj| < prod(p)/2 for the K <= 15 pairwise
-// coprime moduli p <= 256 in use (nu = nu(K, T): 50 / 54 / 58 for K = 13 / 14 / 15).  S is computed modulo each p -- one int8 GEMM per
+// coprime moduli p <= 256 in use (limit = sqrt(prod(p)/2) less the rounding slack: 2^46.9 / 2^50.8 / 2^54.6 / 2^58.4 for K = 12..15).  S is computed modulo each p -- one int8 GEMM per
 // modulus on residues that fit a signed byte, int32 accumulation (re-reduced mod p every 128 000 time bins) -- and reconstructed exactly by
 // the Chinese remainder theorem;  J_ij = S_ij / (sA_i sB_nj).  The only approximation is the rounding of the operands to integers: with
-// independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_nj|^-2) / 12) |a_i||b_nj|, i.e. <= 7.3e-16 |a_i||b_j|
-// at K = 13, <= 4.6e-17 at K = 14 for ordinary columns (a column whose norm is one outlier element is held at 2^49..2^50 by the element
-// bound at every K) -- for ANY data: the precision is pinned to the column norms, not to the column maxima.
+// independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_nj|^-2) / 12) |a_i||b_nj|, i.e. 2.1e-16 |a_i||b_j|
+// at K = 13, 1.5e-17 at K = 14 for ordinary columns (a column whose norm is one outlier element is held at 2^50 by the element bound at
+// every K: 3.6e-16) -- for ANY data: the precision is pinned to the column norms, not to the column maxima.
 //
 //   i8_colstats_kernel max_t |v| and sum_t v^2 per column of X (once per data set) and of omega_g X (per neuron and sweep), deterministic
-//   i8_scales_kernel   the power-of-two scale of every column from those statistics
+//   i8_scales_kernel   the scale of every column from those statistics
 //   i8_planes_kernel   fp64 (t-major) -> K residue planes in BLOCKED layout [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once
 //                      per data set), PB[g] for omega_g X (per neuron, per sweep); one pass over X per group of neurons; residues by four
 //                      fp64 operations each (no integer division)
@@ -22,6 +22,7 @@
 //   i8_crt_kernel      K residues -> mixed-radix digits (Garner) -> fp64 by Horner -> unscaled into the lower triangle of J
 #include "pgl_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -59,8 +60,8 @@ constexpr int ELEM_BITS = 50;          // |scaled element| < 2^50: the residue t
 // ------------------------------------------------------------------ column statistics of V = X (Om == null) or omega_g X
 // amax[g][c] = max_t |v_tc|, ss[g][c] = sum_t v_tc^2 for the G <= 8 weight columns of a group in ONE pass over X.  A workgroup owns 16
 // columns for all T (16 x 64 threads: column = tid % 16, time lane = tid / 16), so the sums are formed in a fixed order -- no atomics:
-// the scales, and with them every bit of J, do not depend on launch timing.  A NaN / inf sticks in amax (the Gram of that column is
-// then NaN, as on the fp64 kernel).
+// the scales, and with them every bit of J, do not depend on launch timing.  A NaN / inf in a column makes its sum of squares
+// non-finite; i8_scales_kernel turns that into a NaN scale (the Gram of that column is then NaN, as on the fp64 kernel).
 constexpr int CS_COLS = 16, CS_LANES = 64, CS_G = 8, CS_ROWS = 4;     // a pass stages CS_LANES * CS_ROWS = 256 time bins of omega
 template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const double* __restrict__ X, long ldx, const double* __restrict__ Om,
@@ -94,8 +95,7 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const double v = WEIGHTED ? x[r] * oms[tl + r * CS_LANES][g] : x[r];       // the same product the planes kernel rounds
-                const double av = fabs(v);
-                m[g] = ((av > m[g]) | (av != av)) ? av : m[g];
+                m[g] = fmax(m[g], fabs(v));               // (a NaN is dropped here and caught through the sum of squares)
                 q[g] = fma(v, v, q[g]);
             }
     }
@@ -108,8 +108,7 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
         if (tl == 0 && live) {                   // one thread per column folds the 64 time lanes in order
             double mm = 0.0, qq = 0.0;
             for (int k = 0; k < CS_LANES; ++k) {
-                const double v = red[0][k][cl];
-                mm = ((v > mm) | (v != v)) ? v : mm;
+                mm = fmax(mm, red[0][k][cl]);
                 qq += red[1][k][cl];
             }
             amax[(long)g * D + c] = mm;
@@ -118,9 +117,9 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
     }
 }
 
-// scale[k] = 2^e, e the largest exponent with  sqrt(ss) 2^e < 2^nu  and  amax 2^e < 2^ELEM_BITS  (1 for an empty column, NaN for a
-// non-finite one)
-__global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict__ amax, const double* __restrict__ ss, long n, int nu,
+// scale[k] = min(limit / |v|_2, 2^ELEM_BITS (1 - 2^-30) / max|v|): the integer column gets the largest norm the CRT range allows
+// (`limit`, pgl_k_i8_norm_limit) unless its largest element would reach 2^50.  1 for an empty column, NaN for a non-finite one.
+__global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict__ amax, const double* __restrict__ ss, long n, double limit,
                                                         double* __restrict__ scale) {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
@@ -128,11 +127,9 @@ __global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict
     double s = 1.0;
     if (!(a < HUGE_VAL) || !(nrm < HUGE_VAL)) s = __builtin_nan("");
     else if (a > 0.0) {
-        int exa, exn;
-        (void)frexp(a, &exa);                                            // a = m 2^exa, m in [0.5, 1)
-        (void)frexp(nrm > a ? nrm : a, &exn);
-        const int e = min(ELEM_BITS - exa, nu - exn);
-        s = ldexp(1.0, e);
+        const double cap = ldexp(1.0 - ldexp(1.0, -30), ELEM_BITS);
+        const double nn = nrm > a ? nrm : a;
+        s = fmin(limit / nn, cap / a) * (1.0 - ldexp(1.0, -40));        // (the two quotients round to nearest: stay on the safe side)
     }
     scale[k] = s;
 }
@@ -227,6 +224,8 @@ struct GramArgs {
     const int8_t* PB;                     // [G][np] planes
     int8_t* R;                            // [G][np][Dq][Dq]
     int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
+    int by_neuron;                        // work lists: XCD y owns neuron y (G == 8)
+    int kt0;                              // 320-tile kernel only: first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
 };
 
@@ -388,6 +387,153 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
             }
 }
 
+// ------------------------------------------------------------------ the same product on 320 x 320 tiles, ONE wave per SIMD
+// Under the package power limit the rate is set by the energy per operation, and a third of the 256 x 256
+// kernel's energy is operand movement.  This variant holds a 320 x 320 tile per workgroup: 4 waves = 2 x 2, wave tile 160 x 160 = 10 x 10
+// accumulators of 16 x 16 -- 400 accumulator registers per lane, which only fit with one wave per SIMD and BOTH register files: the
+// first 64 accumulators live in AGPRs, the other 36 in VGPRs.  hipcc will not split MFMA accumulators over the two files on its own
+// (it picks the AGPR form for the whole function and shuttles the overflow with v_accvgpr moves), so the MFMAs are issued as inline
+// assembly with register-class constraints ("+a" / "+v"); everything else -- LDS reads, DMA requests, addressing -- stays C++.
+// Per K tile and wave: 100 MFMAs for 20 fragment reads (0.20 per MFMA instead of 0.375) and 10 DMA requests (L2 -> LDS bytes per
+// operation -20 %).  Four LDS stages of 640 rows x 64 B (all 160 KiB of the CU), requests two tiles ahead; the B fragments are single-buffered (each is reloaded for the next tile one
+// MFMA after its last use), the A fragments rotate through five register sets, read two rows ahead.  One barrier per K tile, after row 4:
+// it publishes tile kt+1 (whose fragments are first read in rows 8 and 9) and frees the stage of tile kt-1 for the requests of tile kt+3.
+constexpr int BT = 320, BROWS = 2 * BT;
+constexpr int BSTAGE = BROWS * BKB;                          // 40 KiB; 4 stages = 160 KiB: the whole LDS of a CU (the work ticket aliases stage 0 between items)
+
+template <int IDX>
+__device__ __forceinline__ void big_mfma(v4i& acc, const v4i& a, const v4i& b) {
+    if constexpr (IDX < 64) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+template <int I, int J, typename F>
+__device__ __forceinline__ void big_rows(v4i (&acc)[10][10], v4i (&FA)[5], v4i (&FB)[10], F&& slot) {
+    if constexpr (I < 10) {
+        big_mfma<I * 10 + J>(acc[I][J], FA[I % 5], FB[J]);
+        slot(std::integral_constant<int, I>{}, std::integral_constant<int, J>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (J == 9) big_rows<I + 1, 0>(acc, FA, FB, slot);
+        else big_rows<I, J + 1>(acc, FA, FB, slot);
+    }
+}
+
+template <int BNST>
+__device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds) {
+    const int m0 = tm * BT, n0 = tn * BT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long plane = (long)g.Dq * g.Kp;
+    const int8_t* A = g.PA + (long)q * plane;
+    const int8_t* B = g.PB + ((long)gz * g.np + q) * plane;
+    const int nkt = (int)(g.Kp / BKB);
+    // DMA: per K tile 640 rows x 64 B = 40 requests of 1 KiB; wave w issues requests w, w+4, ..., w+36 (row blocks 0..19 = A, 20..39 = B).
+    // A request = wave-uniform base (scalar registers) + one per-lane byte offset shared by all requests
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ chunk_swz((lane >> 4) & 3)) * 16));
+    const int fr = lane & 15, fc = lane >> 4;
+    auto frag = [&](int stage, int row) {
+        const int pc = fc ^ chunk_swz((row >> 2) & 3);
+        return *reinterpret_cast<const v4i*>(lds + stage * BSTAGE + row * BKB + pc * 16);
+    };
+    auto rdA = [&](int stage, int f) { return frag(stage, wm * 160 + f * 16 + fr); };
+    auto rdB = [&](int stage, int f) { return frag(stage, BT + wn * 160 + f * 16 + fr); };
+    const double pq = (double)c_mod[q], ipq = 1.0 / pq;
+    auto reduce = [&](int v) {                              // symmetric representative of v mod p (exact: |v| < 2^31)
+        const double x = (double)v;
+        return (int)fma(-pq, rint(x * ipq), x);
+    };
+    int8_t* R = g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
+    // long data sets: the host launches one pass per chunk of KCH K tiles (the int32 sums cannot overflow within one); a pass adds its
+    // residues to the previous passes' through the output bytes.  (A chunk loop in here makes hipcc spill the 400 accumulators.)
+    {
+        const int kc = g.kt0;
+        const int nk = min(nkt - kc, KCH);
+        const char* sb[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int rq = wv + 4 * i;
+            const int8_t* base = rq < 20 ? A + (long)(m0 + 16 * rq) * g.Kp : B + (long)(n0 + 16 * (rq - 20)) * g.Kp;
+            sb[i] = reinterpret_cast<const char*>(base) + (long)kc * 1024;
+        }
+        long gadv = nk >= 2 ? 1024 : 0;   // 0 once the pass's last tile has been requested: the cursors stop (redundant re-requests into a dead stage)
+        auto dma_piece = [&](int stage, int i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sb[i] + voff), (lds_ptr_t)(lds + stage * BSTAGE + (wv + 4 * i) * 1024), 16, 0, 0);
+            sb[i] += gadv;
+        };
+        v4i acc[10][10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+        // prologue: tiles 0 .. BNST-2 of the pass
+#pragma unroll
+        for (int i = 0; i < 10; ++i) dma_piece(0, i);
+        if (nk < 3) gadv = 0;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) dma_piece(1, i);
+        if constexpr (BNST == 4) {
+            if (nk < 4) gadv = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) dma_piece(2, i);
+            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // tile 0 has landed
+        } else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        v4i FA[5], FB[10];
+#pragma unroll
+        for (int f = 0; f < 10; ++f) FB[f] = rdB(0, f);
+        FA[0] = rdA(0, 0);
+        FA[1] = rdA(0, 1);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // accumulator initialisation (VALU writes) ahead of the first MFMA
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nxt = cur == BNST - 1 ? 0 : cur + 1;
+            const int dst = cur == 0 ? BNST - 1 : cur - 1;           // the stage of tile kt-1 takes tile kt + BNST - 1
+            if (kt + BNST >= nk) gadv = 0;
+            big_rows<0, 0>(acc, FA, FB, [&](auto ic, auto jc) {
+                constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
+                // A fragment of row I+2 (rows 10, 11 = rows 0, 1 of the next tile), two rows ahead; five register sets in rotation
+                // (10 rows = 2 x 5: the rotation comes back to set 0 at every tile)
+                if constexpr (J == 1) { if constexpr (I + 2 < 10) FA[(I + 2) % 5] = rdA(cur, I + 2); else FA[(I + 2) % 5] = rdA(nxt, I + 2 - 10); }
+                // mid-tile: tile kt+1 has landed (own requests; the 10 of tile kt+2 may stay in flight), everybody is past tile kt-1
+                if constexpr (I == 4 && J == 0) {
+                    if constexpr (BNST == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                // requests of tile kt + BNST - 1: two per row in rows 4..8
+                if constexpr (I >= 4 && I <= 8 && (J == 3 || J == 7)) dma_piece(dst, 2 * (I - 4) + (J == 7));
+                // B fragments of the next tile: fragment J-1 one MFMA after its last use (row 9); fragment 9 below
+                if constexpr (I == 9 && J >= 1) FB[J - 1] = rdB(nxt, J - 1);
+            });
+            FB[9] = rdB(nxt, 9);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // last (redundant) requests landed; MFMA results readable
+        __builtin_amdgcn_s_barrier();                      // every wave is done with the stages before the next item refills them
+        auto store = [&](auto accum_c) {
+            constexpr bool ACCUM = decltype(accum_c)::value;
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + wm * 160 + i * 16 + 4 * (lane >> 4) + r;
+                        const int col = n0 + wn * 160 + j * 16 + (lane & 15);
+                        int8_t* dst8 = R + (long)row * g.Dq + col;
+                        int v = reduce(acc[i][j][r]);
+                        if constexpr (ACCUM) v = reduce(v + (int)*dst8);
+                        *dst8 = (int8_t)(v & 0xff);          // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
+                    }
+        };
+        if (kc == 0) store(std::false_type{});
+        else store(std::true_type{});
+    }
+}
+
 // persistent: one workgroup per CU pulls (neuron of the group, plane, tile in clustered order) items from per-XCD work lists; a workgroup
 // reads the XCC it runs on and takes the next item of that XCD's list, stealing from the next XCD when its own list is exhausted.
 //   G == 8 (every full group): XCD y owns NEURON y -- its list is that neuron's (plane, tile) items in order.  The 32 workgroups of an
@@ -396,14 +542,15 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
 //     stream, identical for all neurons) are fetched from HBM once and found in the memory-side cache by the other seven.
 //   otherwise: the flat item list is cut into chunks of CH, chunk c belongs to XCD c % 8.
 // Placement is used for speed only -- any placement gives the same result.
-__global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
+template <bool BIG, int BNST = 4>
+__global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    int* ticket = reinterpret_cast<int*>(lds + NST * STAGE_BYTES);
-    const int ntm = g.Dq / TM;
+    int* ticket = reinterpret_cast<int*>(lds + (BIG ? 0 : NST * STAGE_BYTES));      // (320 tiles: aliases stage 0, which is idle between items)
+    const int ntm = g.Dq / (BIG ? BT : TM);
     const int ntiles = ntm * (ntm + 1) / 2;
     const int per_neuron = ntiles * g.np;
     const int total = per_neuron * g.G;
-    const bool by_neuron = g.G == 8;
+    const bool by_neuron = g.by_neuron != 0;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
@@ -431,7 +578,10 @@ __global__ __launch_bounds__(512) void i8_gram_kernel(GramArgs g) {
         if (ticket[0] < 0) break;
         const int pair = __builtin_amdgcn_readfirstlane(ticket[1]);
         const int tm = __builtin_amdgcn_readfirstlane(ticket[2]), tn = __builtin_amdgcn_readfirstlane(ticket[3]);
-        i8_gram_item(g, pair / g.np, pair % g.np, tm, tn, lds);
+        if constexpr (BIG) {
+            __syncthreads();                               // the ticket lives in stage 0: everybody has read it before the first request lands there
+            i8_gram_item_big<BNST>(g, pair / g.np, pair % g.np, tm, tn, lds);
+        } else i8_gram_item(g, pair / g.np, pair % g.np, tm, tn, lds);
     }
 }
 
@@ -479,15 +629,29 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------ host side
+// Tile edge of the product kernel: 320 (one wave per SIMD, accumulators in both register files) or 256 (two waves per SIMD);
+// PGL_I8_TILE=256 selects the latter.  Planes and residues are padded to a multiple of it (pgl_i8_padded_rows).
+static int pgl_i8_tile() {
+    static const int t = [] { const char* e = getenv("PGL_I8_TILE"); return (e && atoi(e) == 256) ? 256 : 320; }();
+    return t;
+}
+int pgl_k_i8_padded_rows(int D) { const int t = pgl_i8_tile(); return (D + t - 1) / t * t; }
+
 // time bins per plane row: a multiple of the 64-byte K tile, at least four tiles (the Gram pipeline keeps three requested ahead)
 static long pgl_i8_kp(int T) { const long k = ((long)T + 63) / 64 * 64; return k < 256 ? 256 : k; }
 
-// nu(K, T): the columns' integer norms are kept below 2^nu, the largest integer with (2^nu (1 + 1e-9) + sqrt(T)/2 + 1)^2 <= prod(p_0..p_{K-1}) / 2
-// (rounding a column to integers adds at most sqrt(T)/2 to its norm), so |S_ij| <= |A_i||B_j| stays inside the symmetric CRT range
-int pgl_k_i8_nu(int nplanes, int T) {
+// The integer columns' norms are kept at or below limit(K, T), the largest value with
+//     (limit (1 + 1e-9) + 0.75 sqrt(T) + 1)^2 <= prod(p_0..p_{K-1}) / 2
+// (rounding a scaled column to integers adds at most sqrt(T)/2 to its norm, the fp64 product x * scale another sqrt(T)/8 at most), so
+// |S_ij| <= |A_i||B_j| stays inside the symmetric CRT range.  nu = floor(log2(limit)): 46 / 50 / 54 / 58 for K = 12 / 13 / 14 / 15.
+double pgl_k_i8_norm_limit(int nplanes, int T) {
     double l2 = 0.0;
     for (int q = 0; q < nplanes && q < NP; ++q) l2 += std::log2((double)MT.p[q]);
-    const double lim = (std::exp2((l2 - 1.0) * 0.5) - 0.5 * std::sqrt((double)(T < 1 ? 1 : T)) - 1.0) / (1.0 + 1e-9);
+    const double lim = (std::exp2((l2 - 1.0) * 0.5) - 0.75 * std::sqrt((double)(T < 1 ? 1 : T)) - 1.0) / (1.0 + 1e-9);
+    return lim > 0.0 ? lim : 0.0;
+}
+int pgl_k_i8_nu(int nplanes, int T) {
+    const double lim = pgl_k_i8_norm_limit(nplanes, T);
     if (!(lim >= 2.0)) return 0;
     return (int)std::floor(std::log2(lim) - 1e-12);
 }
@@ -500,11 +664,11 @@ int pgl_k_i8_min_planes(int T) {
 }
 
 size_t pgl_k_i8_plane_bytes(int D, int T) {
-    const long Dq = (D + 255) / 256 * 256, Kp = pgl_i8_kp(T);
+    const long Dq = pgl_k_i8_padded_rows(D), Kp = pgl_i8_kp(T);
     return (size_t)NP * Dq * Kp;
 }
 size_t pgl_k_i8_residue_bytes(int D) {
-    const long Dq = (D + 255) / 256 * 256;
+    const long Dq = pgl_k_i8_padded_rows(D);
     return (size_t)NP * Dq * Dq;
 }
 
@@ -520,9 +684,8 @@ int pgl_k_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int
 }
 
 int pgl_k_i8_scales(const double* amax, const double* ss, long n, int T, int nplanes, double* scale, hipStream_t st) {
-    const int nu = pgl_k_i8_nu(nplanes, T);
-    if (nu < 8) { pgl_set_error("i8 scales: %d moduli leave no room for T = %d", nplanes, T); return PGL_ERR_ARG; }
-    hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amax, ss, n, nu, scale);
+    if (pgl_k_i8_nu(nplanes, T) < 8) { pgl_set_error("i8 scales: %d moduli leave no room for T = %d", nplanes, T); return PGL_ERR_ARG; }
+    hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amax, ss, n, pgl_k_i8_norm_limit(nplanes, T), scale);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
@@ -530,7 +693,7 @@ int pgl_k_i8_scales(const double* amax, const double* ss, long n, int T, int npl
 // residue planes of X (Om == null, G = 1) or of omega_g X for the G weight columns Om[:, 0..G)
 int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, int8_t* P, int T, int D, int G, int nplanes,
                     hipStream_t st) {
-    const int Dq = (D + 255) / 256 * 256;
+    const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     PlaneArgs a{X, ldx, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
     hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + PT_T - 1) / PT_T), Dq / PT_D), dim3(256), 0, st, a, G);
@@ -539,25 +702,36 @@ int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const
 }
 
 int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, int G, int nplanes, hipStream_t st) {
-    const int Dq = (D + 255) / 256 * 256;
+    const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
-    static PglPerDevice attr;
-    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel), GRAM_LDS, attr)) return rc;
+    const bool big = pgl_i8_tile() == BT;
+    static const int big_stages = [] { const char* e = getenv("PGL_I8_STAGES"); return (e && atoi(e) == 3) ? 3 : 4; }();      // A/B switch
+    static PglPerDevice attr, attr_big3, attr_big4;
+    if (big && big_stages == 4) { if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<true, 4>), 4 * BSTAGE, attr_big4)) return rc; }
+    else if (big) { if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<true, 3>), 3 * BSTAGE, attr_big3)) return rc; }
+    else if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<false>), GRAM_LDS, attr)) return rc;
     const int n_cu = pgl_device_cus(pgl_device());
-    const int ntm = Dq / TM, ntiles = ntm * (ntm + 1) / 2;
+    const int ntm = Dq / (big ? BT : TM), ntiles = ntm * (ntm + 1) / 2;
     const long total = (long)ntiles * nplanes * G;
     if (total <= 0) return PGL_OK;
     if (total > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
-    GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, pgl_sched_slot(st)};
-    if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
-    hipLaunchKernelGGL(i8_gram_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), GRAM_LDS, st, g);
-    PGL_CHECK_LAUNCH();
+    const unsigned grid = (unsigned)(total < n_cu ? total : n_cu);
+    const int nkt = (int)(Kp / BKB);
+    for (int kt0 = 0; kt0 < (big ? nkt : 1); kt0 += KCH) {
+        static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();   // A/B switch: "chunk"
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, kt0, pgl_sched_slot(st)};
+        if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
+        if (big && big_stages == 4) hipLaunchKernelGGL((i8_gram_kernel<true, 4>), dim3(grid), dim3(256), 4 * BSTAGE, st, g);
+        else if (big) hipLaunchKernelGGL((i8_gram_kernel<true, 3>), dim3(grid), dim3(256), 3 * BSTAGE, st, g);
+        else hipLaunchKernelGGL(i8_gram_kernel<false>, dim3(grid), dim3(512), GRAM_LDS, st, g);
+        PGL_CHECK_LAUNCH();
+    }
     return PGL_OK;
 }
 
 int pgl_k_i8_crt(const int8_t* R, const double* sA, const double* sB, double* J, long ldj, long strideJ, int D, int G, int nplanes, int accumulate,
                  hipStream_t st) {
-    const int Dq = (D + 255) / 256 * 256;
+    const int Dq = pgl_k_i8_padded_rows(D);
     if (G <= 0) return PGL_OK;
     CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes};
     hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 255) / 256, D, G), dim3(256), 0, st, c);

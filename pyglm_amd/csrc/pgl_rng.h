@@ -150,14 +150,15 @@ __device__ __forceinline__ double pgl_gamma(double alpha, PglPhilox& r) {
 #define PGL_PG_SERIES_TERMS 32
 #define PGL_PG_DEVROYE_MAX 12
 
-// sum_{k > K} ((k - 1/2)^2 + c)^-p for p = 1, 2 by the midpoint-rule identity  sum_k phi(k - 1/2) = int_K^inf phi + phi'(K) / 24 + O(K^-(2p+3))
+// sum_{k > K} ((k - 1/2)^2 + c)^-p for p = 1, 2 by the midpoint-rule (Euler-Maclaurin) identity
+//     sum_{k > K} phi(k - 1/2) = int_K^inf phi + phi'(K) / 24 - 7 phi'''(K) / 5760 + O(phi^(5)(K)):   relative error < 2e-9 at K = 32
 __device__ __forceinline__ void pgl_pg_tail_sums(double c, double& S1, double& S2) {
-    const double K = (double)PGL_PG_SERIES_TERMS, q = K * K + c, sc = sqrt(c);
+    const double K = (double)PGL_PG_SERIES_TERMS, q = K * K + c, sc = sqrt(c), iq = 1.0 / q, iq2 = iq * iq;
     const double at = sc > 1e-6 * K ? atan(sc / K) / sc : 1.0 / K - c / (3.0 * K * K * K);          // int_K^inf dx / (x^2 + c)
-    S1 = at - 2.0 * K / (24.0 * q * q);
-    const double i2 = c > 1e-3 * K * K ? (at - K / q) / (2.0 * c)                                    // int_K^inf dx / (x^2 + c)^2
+    S1 = at + (-2.0 * K * iq2) * (1.0 / 24.0) - (-24.0 * K * (K * K - c) * iq2 * iq2) * (7.0 / 5760.0);
+    const double i2 = c > 1e-3 * K * K ? (at - K * iq) / (2.0 * c)                                   // int_K^inf dx / (x^2 + c)^2
                                        : 1.0 / (3.0 * K * K * K) - 2.0 * c / (5.0 * K * K * K * K * K) + 3.0 * c * c / (7.0 * K * K * K * K * K * K * K);
-    S2 = i2 - 4.0 * K / (24.0 * q * q * q);
+    S2 = i2 + (-4.0 * K * iq2 * iq) * (1.0 / 24.0) - (72.0 * K * iq2 * iq2 - 192.0 * K * K * K * iq2 * iq2 * iq) * (7.0 / 5760.0);
 }
 
 __device__ __forceinline__ double pgl_pg_series(double b, double z, PglPhilox& r) {

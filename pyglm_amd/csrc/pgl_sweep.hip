@@ -11,6 +11,7 @@
 #include "pgl_common.h"
 #include "../../include/pyglm_hip.h"
 #include <cmath>
+#include <cstdlib>
 #include <tuple>
 #include <vector>
 
@@ -134,6 +135,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     const int Dp = r_up(D + 1, 16), ldn = r_up(nloc, 2), ldj = r_up(D + 2, 16);
     const long strideJ = (long)ldj * ldj;
     const int R = pgl_k_flip_window_blocks(B);
+    const int kmax = pgl_k_flip_kmax();
     if (R < 1) { pgl_set_error("B=%d too large for the proposal window", B); return PGL_ERR_ARG; }
     bool any_i8 = false;
     for (int i = 0; i < s->ndatasets; ++i) {
@@ -249,9 +251,10 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
             else if (hipMemcpyAsync(s->Mtab, s->Jbuf, (size_t)nbb * strideJ * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
                 pgl_set_error("tableau copy failed"); return PGL_ERR_HIP;
             }
-            // initial sweep on S0 = {bias} U {active blocks}, in chunks of 256 pivots; the lists come from the device
+            // initial sweep on S0 = {bias} U {active blocks}, in chunks of 512 pivots (rank-512 passes); the lists come from the device
             RC(pgl_k_flip_pivot_list(fs, s->act, D + 1, s->na, st));
-            const int ck = 256;
+            static const int ck_env = [] { const char* e = getenv("PGL_FLIP_CHUNK"); return e ? atoi(e) : 0; }();      // A/B switch
+            const int ck = (ck_env >= 16 && ck_env <= kmax) ? ck_env : kmax;
             long rows = s->init_rows_bound > 0 && s->init_rows_bound <= D + 1 ? s->init_rows_bound : D + 1;
             for (int c = 0; (long)c * ck < rows; ++c) {
                 const long left = rows - (long)c * ck;

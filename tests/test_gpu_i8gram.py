@@ -11,11 +11,14 @@ MODULI = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 
 ELEM_BITS = 50
 
 
-def _nu(k, T):
-    """bits of the integer column norms (pgl_i8gram.hip: pgl_k_i8_nu): (2^nu (1 + 1e-9) + sqrt(T)/2 + 1)^2 <= prod(p[:k]) / 2"""
+def _limit(k, T):
+    """norm of the integer columns (pgl_i8gram.hip: pgl_k_i8_norm_limit): (limit (1 + 1e-9) + 0.75 sqrt(T) + 1)^2 <= prod(p[:k]) / 2"""
     l2 = sum(np.log2(p) for p in MODULI[:k])
-    lim = (2.0 ** ((l2 - 1.0) * 0.5) - 0.5 * np.sqrt(T) - 1.0) / (1.0 + 1e-9)
-    return int(np.floor(np.log2(lim) - 1e-12))
+    return (2.0 ** ((l2 - 1.0) * 0.5) - 0.75 * np.sqrt(T) - 1.0) / (1.0 + 1e-9)
+
+
+def _nu(k, T):
+    return int(np.floor(np.log2(_limit(k, T)) - 1e-12))
 
 
 def _planes(P, n, Dq, Kp):
@@ -51,7 +54,7 @@ def _scales(Xd, Od, T, D, G, k):
     call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), G * D, T, k, ptr(sB), None)
     torch.cuda.synchronize()
     Om = Od.cpu().numpy()
-    nu = _nu(k, T)
+    lim, cap = _limit(k, T), 2.0 ** ELEM_BITS
     for g in range(G):
         V = Om[:, g:g + 1] * X
         np.testing.assert_array_equal(stat[0, g].cpu().numpy(), np.abs(V).max(0))
@@ -60,10 +63,8 @@ def _scales(Xd, Od, T, D, G, k):
         amax, nrm = np.abs(V).max(0), np.sqrt((V * V).sum(0))
         live = amax > 0
         assert np.all(sc[~live] == 1.0)
-        m, e = np.frexp(sc[live])
-        assert np.all(m == 0.5)                                                     # powers of two
-        assert np.all(amax[live] * sc[live] < 2.0 ** ELEM_BITS) and np.all(nrm[live] * sc[live] * (1 + 1e-12) < 2.0 ** nu)
-        assert np.all((amax[live] * sc[live] * 2 >= 2.0 ** ELEM_BITS) | (nrm[live] * sc[live] * 2 * (1 + 3e-12) >= 2.0 ** nu))   # and maximal
+        assert np.all(amax[live] * sc[live] < cap) and np.all(nrm[live] * sc[live] <= lim)         # element bound, norm bound
+        assert np.all((amax[live] * sc[live] >= cap * (1 - 1e-8)) | (nrm[live] * sc[live] >= lim * (1 - 1e-8)))           # and maximal
     return sA, sB
 
 
@@ -73,7 +74,7 @@ def test_norm_bits_and_minimum_planes():
     assert lib.pgl_i8_max_planes() == 15
     for k in range(8, 16):
         for T in (300, 100000, 5000000):
-            assert lib.pgl_i8_norm_bits(k, T) == _nu(k, T)
+            assert lib.pgl_i8_norm_bits(k, T) == _nu(k, T) and abs(lib.pgl_i8_norm_limit(k, T) / _limit(k, T) - 1) < 1e-12
     assert [lib.pgl_i8_norm_bits(k, 100000) for k in (12, 13, 14, 15)] == [46, 50, 54, 58]
     assert lib.pgl_i8_min_planes(100000) == 13 and lib.pgl_i8_min_planes(50) == 13
 
@@ -86,8 +87,8 @@ def test_residue_planes_match_numpy(k):
     X, Om = _data(T, D, G)
     Xd, Od = torch.from_numpy(X).cuda(), torch.from_numpy(Om).cuda()
     lib = load()
-    Dq, Kp = 256, 320
-    assert lib.pgl_i8_plane_bytes(D, T) == 15 * Dq * Kp and lib.pgl_i8_residue_bytes(D) == 15 * Dq * Dq
+    Dq, Kp = lib.pgl_i8_padded_rows(D), 320
+    assert Dq in (256, 320) and lib.pgl_i8_plane_bytes(D, T) == 15 * Dq * Kp and lib.pgl_i8_residue_bytes(D) == 15 * Dq * Dq
     sA, sB = _scales(Xd, Od, T, D, G, k)
     PA = torch.full((k * Dq * Kp,), 77, dtype=torch.int8, device="cuda:0")
     PB = torch.full((G * k * Dq * Kp,), 77, dtype=torch.int8, device="cuda:0")
@@ -134,7 +135,7 @@ def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G, k):
     sA, sB = sAd.cpu().numpy(), sBd.cpu().numpy()
     # (a) the exact integer answer: S = A'B on the scaled integers (Python ints), J = S / (sA sB)
     IA = np.rint(X * sA[None, :]).astype(np.int64)
-    nu = _nu(k, T)
+    lim = _limit(k, T)
     for g in (0, G - 1):
         IB = np.rint((Om[:, g:g + 1] * X) * sB[g][None, :]).astype(np.int64)
         # Cauchy-Schwarz keeps every entry inside the symmetric CRT range
@@ -142,7 +143,7 @@ def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G, k):
         nB = np.sqrt((IB.astype(np.longdouble) ** 2).sum(0))
         assert float(nA.max() * nB.max()) < 0.5 * float(np.prod([np.longdouble(p) for p in MODULI[:k]]))
         live = np.abs(X).max(0) > 0
-        assert np.all(nA[live] >= 2.0 ** (min(nu, ELEM_BITS) - 1) - np.sqrt(T)) and np.all(nA < 2.0 ** nu + np.sqrt(T))
+        assert np.all(nA[live] >= min(lim, 2.0 ** ELEM_BITS) * (1 - 1e-6) - np.sqrt(T)) and np.all(nA <= lim * (1 + 1e-9) + 0.75 * np.sqrt(T))
         cols = [0, 1, 2, 5, D // 2, D - 1]
         S = IA.astype(object).T.dot(IB[:, cols].astype(object))                       # exact big-integer product, (D, len(cols))
         for c, j in enumerate(cols):
@@ -161,8 +162,9 @@ def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G, k):
     torch.cuda.synchronize()
     Jn = Jn.cpu().numpy()[:, :D, :D]
     low = np.tril(np.ones((D, D), dtype=bool))
-    # standard deviation of the operand-rounding error relative to |a_i||b_j|: sqrt((|A_i|^-2 + |B_j|^-2) / 12), worst case both norms 2^(nu-1)
-    sigma = np.sqrt(2.0 / 12.0) / 2.0 ** (min(nu, ELEM_BITS) - 1)
+    # standard deviation of the operand-rounding error relative to |a_i||b_j|: sqrt((|A_i|^-2 + |B_j|^-2) / 12); the smallest norms are
+    # the element-bound ones (2^50) or the limit
+    sigma = np.sqrt(2.0 / 12.0) / min(lim, 2.0 ** ELEM_BITS)
     for g in range(G if D <= 300 else 1):
         ref = np.asarray((Xl * Om[:, g].astype(np.longdouble)[:, None]).T @ Xl, dtype=np.longdouble)
         na = np.sqrt((X * X).sum(0))

@@ -140,10 +140,10 @@ def test_standalone_regression_flow():
     assert ll.shape == (T,) and np.all(np.isfinite(ll))
 
 
-@pytest.mark.parametrize("xi,tol", [(3.0, 1e-12), (2.5, 1e-9), (0.7, 1e-9)])
+@pytest.mark.parametrize("xi,tol", [(3.0, 1e-12), (2.5, 1e-8), (0.7, 1e-8)])
 def test_negative_binomial_sweep_vs_oracle(xi, tol):
     """negative-binomial observations, PG shape b = y + xi (regression.py:479-489): integer xi (Devroye draws only) and real-valued
-    xi (every bin adds a sum-of-gammas draw for the fractional part; 1e-9: the series' remainder moments are computed differently)"""
+    xi (every bin adds a sum-of-gammas draw for the fractional part; 1e-8: the series' remainder moments are computed differently)"""
     from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
     rng = np.random.default_rng(4)
     N, B, T = 10, 2, 900

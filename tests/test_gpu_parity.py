@@ -104,7 +104,7 @@ def test_device_pg_ks_against_gamma_series(torch_dev, b, z):
 
 def test_device_pg_real_shapes_match_oracle(torch_dev):
     """real-valued shapes on a shared stream: the series branch consumes the stream identically on both sides; the remainder's moments are
-    computed by different formulas (closed form on the device, term-by-term sums in the oracle), hence 1e-9 instead of 1e-12"""
+    computed by different formulas (closed form on the device, term-by-term sums in the oracle), hence 1e-8 instead of 1e-12"""
     torch = torch_dev
     from pyglm_amd._lib import call, ptr
     n = 60000
@@ -118,7 +118,7 @@ def test_device_pg_real_shapes_match_oracle(torch_dev):
     got = out.cpu().numpy()
     want = orc.pg_draw(b, z, 9, orc.stream_id(2, 3), 5)
     assert got[0] == 0.0 and np.all(np.isfinite(got)) and np.all(got[1:] > 0)
-    close = np.abs(got - want) <= 1e-9 * np.abs(want) + 1e-300
+    close = np.abs(got - want) <= 1e-8 * np.abs(want) + 1e-300
     assert close.mean() >= 1 - 2e-3, "only %.6f of draws agree" % close.mean()
 
 

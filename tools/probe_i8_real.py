@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Times one group launch of the integer Gram (stats / planes / product / CRT) on the bench's own data (cfg3: basis-filtered Bernoulli(0.08)
+spikes, omega ~ PG(1, psi)) -- residue planes of real data are not uniformly random bytes, and under the package power limit that
+matters.  python tools/probe_i8_real.py [planes=13] [reps=6]"""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from pyglm_amd.engine import GibbsEngine            # noqa: E402
+from pyglm_amd._lib import call, ptr                # noqa: E402
+from pyglm_amd.utils.basis import cosine_basis      # noqa: E402
+
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+N, B, T, nl = 1024, 5, 100000, 8
+rng = np.random.default_rng(0)
+Y = (rng.random((T, N)) < 0.08).astype(float)
+eng = GibbsEngine(N, B, 0, nl, batch=nl, gram="int8", planes=k)
+ds = eng.add_data(Y, basis=cosine_basis(B, L=100) / 100)
+eng._upload_weights(np.ones((nl, N), bool), rng.standard_normal((nl, N, B)) * 0.05, np.full(nl, -2.0))
+with torch.cuda.device(eng.dev):
+    eng._psi_pass(True, 3, 0)
+    D, Dp, ldj = eng.D, eng.Dp, eng.ldj
+    _, _, G, PB, R, stat = eng._i8_scratch
+    om = ctypes.c_void_p(ds.OK.data_ptr())
+    ldo = 2 * eng.ldn
+    J = eng.Jslots[0]
+    stages = [("stats", lambda: (call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, T, D, nl, ptr(stat[0]), ptr(stat[1]), None),
+                                 call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), nl * D, T, k, ptr(stat[2]), None))),
+              ("planes", lambda: call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
+              ("gram", lambda: call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), T, D, nl, k, None)),
+              ("crt", lambda: call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), ptr(J), ldj, ldj * ldj, T, D, nl, k, 0, None))]
+    for name, fn in stages:
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        extra = "   %.1f TOP/s algorithmic" % (k * nl * T * D * (D + 1.0) / ms * 1e-9) if name == "gram" else ""
+        print("%-8s %9.3f ms%s" % (name, ms, extra), flush=True)
+    zeros = float((PB[: ds.PA.numel()] == 0).float().mean())
+    print("zero bytes in the first neuron's planes: %.3f" % zeros)
