@@ -395,11 +395,11 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
 // (it picks the AGPR form for the whole function and shuttles the overflow with v_accvgpr moves), so the MFMAs are issued as inline
 // assembly with register-class constraints ("+a" / "+v"); everything else -- LDS reads, DMA requests, addressing -- stays C++.
 // Per K tile and wave: 100 MFMAs for 20 fragment reads (0.20 per MFMA instead of 0.375) and 10 DMA requests (L2 -> LDS bytes per
-// operation -20 %).  Four LDS stages of 640 rows x 64 B (all 160 KiB of the CU), requests two tiles ahead; the B fragments are single-buffered (each is reloaded for the next tile one
+// operation -20 %).  Three LDS stages of 640 rows x 64 B, requests one tile ahead (a fourth stage is slower, see pgl_k_i8_gram); the B fragments are single-buffered (each is reloaded for the next tile one
 // MFMA after its last use), the A fragments rotate through five register sets, read two rows ahead.  One barrier per K tile, after row 4:
-// it publishes tile kt+1 (whose fragments are first read in rows 8 and 9) and frees the stage of tile kt-1 for the requests of tile kt+3.
+// it publishes tile kt+1 (whose fragments are first read in rows 8 and 9) and frees the stage of tile kt-1 for the requests of tile kt+2.
 constexpr int BT = 320, BROWS = 2 * BT;
-constexpr int BSTAGE = BROWS * BKB;                          // 40 KiB; 4 stages = 160 KiB: the whole LDS of a CU (the work ticket aliases stage 0 between items)
+constexpr int BSTAGE = BROWS * BKB;                          // 40 KiB per stage (the work ticket aliases stage 0 between items)
 
 template <int IDX>
 __device__ __forceinline__ void big_mfma(v4i& acc, const v4i& a, const v4i& b) {
@@ -542,7 +542,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
 //     stream, identical for all neurons) are fetched from HBM once and found in the memory-side cache by the other seven.
 //   otherwise: the flat item list is cut into chunks of CH, chunk c belongs to XCD c % 8.
 // Placement is used for speed only -- any placement gives the same result.
-template <bool BIG, int BNST = 4>
+template <bool BIG, int BNST = 3>
 __global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int* ticket = reinterpret_cast<int*>(lds + (BIG ? 0 : NST * STAGE_BYTES));      // (320 tiles: aliases stage 0, which is idle between items)
@@ -705,7 +705,10 @@ int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, i
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     const bool big = pgl_i8_tile() == BT;
-    static const int big_stages = [] { const char* e = getenv("PGL_I8_STAGES"); return (e && atoi(e) == 3) ? 3 : 4; }();      // A/B switch
+    // LDS stages of the 320-tile kernel: 3 (requests one tile ahead).  A fourth stage (two tiles ahead, all 160 KiB) measured 6.7 % SLOWER on
+    // real planes (107.2 vs 100.5 ms per launch of 8 neurons at cfg3): the 32 workgroups of an XCD then hold 3 x 40 KiB in flight each, which
+    // is the whole 4 MiB L2, and the strips they share fall out of it.  PGL_I8_STAGES=4 keeps the variant measurable.
+    static const int big_stages = [] { const char* e = getenv("PGL_I8_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
     static PglPerDevice attr, attr_big3, attr_big4;
     if (big && big_stages == 4) { if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<true, 4>), 4 * BSTAGE, attr_big4)) return rc; }
     else if (big) { if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<true, 3>), 3 * BSTAGE, attr_big3)) return rc; }

@@ -322,7 +322,12 @@ class GibbsEngine(object):
             return False
         free, _ = torch.cuda.mem_get_info(self.dev)
         have = self._i8_scratch[0] if self._i8_scratch else 0
-        return _lib.load().pgl_i8_plane_bytes(self.D, T) + max(0, self._i8_need(T, 1) - have) < 0.8 * free
+        fits = _lib.load().pgl_i8_plane_bytes(self.D, T) + max(0, self._i8_need(T, 1) - have) < 0.8 * free
+        if not fits:
+            import warnings
+            warnings.warn("gram='auto': the residue planes of this data set (D = %d, T = %d) do not fit in the %.0f GB free on %s; its likelihood "
+                          "Gram runs on the fp64 MFMA kernel" % (self.D, T, free / 1e9, self.dev), RuntimeWarning, stacklevel=3)
+        return fits
 
     def _i8_reserve(self, T):
         """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the longest data set seen so far"""
@@ -342,6 +347,16 @@ class GibbsEngine(object):
                             self._z(3, G, self.D))          # per group: column maxima, sums of squares, scales of omega_g X
 
     @_on_device
+    @_on_device
+    def drop_int8(self, i):
+        """put data set i on the fp64 Gram kernel and release its residue planes (the population model does this on every rank when ANY
+        rank could not take the integer path, so that the choice never depends on the rank)"""
+        ds = self.datasets[i]
+        if ds.int8:
+            ds.int8 = False
+            ds.PA = ds.sA = None
+            torch.cuda.empty_cache()
+
     def set_noise(self, eta):
         """noise variances eta (nloc,) of the Gaussian observation model (regression.py:380-398)"""
         assert self.obs == 2

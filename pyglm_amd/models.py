@@ -113,7 +113,18 @@ class NonlinearAutoregressiveModel(object):
         T = data.shape[0]
         if X is not None:
             assert X.shape == (T, N, B)
-        self.engine.add_data(data, X=X, basis=self.basis)
+        ds = self.engine.add_data(data, X=X, basis=self.basis)
+        dist = _dist()
+        if dist is not None and hasattr(self.engine, "drop_int8"):
+            # gram="auto" looks at the free memory of ITS GPU: make the choice collective (integer path only if every rank can take it), so
+            # that results never depend on which rank a neuron lives on
+            import torch
+            t = torch.tensor([int(bool(getattr(ds, "int8", False)))], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                t = t.to(self._comm_dev())
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if not int(t.item()):
+                self.engine.drop_int8(len(self.engine.datasets) - 1)
         self.data_list.append((_LazyX(self.engine, len(self.engine.datasets) - 1) if X is None else X, data))
 
     # ---- local <-> global state
