@@ -217,7 +217,7 @@ constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
 constexpr int STAGE_BYTES = (TM + TN) * BKB;
 constexpr int GRAM_LDS = NST * STAGE_BYTES + 16;             // + the work ticket
 constexpr int KCH = 2000;                                    // K tiles between re-reductions: 128 + 128000 * 128 * 128 < 2^31
-constexpr int SB = 6, CH = 32;                               // clustered tile order: super-blocks of SB x SB tiles; work-list chunk per XCD
+constexpr int CH = 32;                               // clustered tile order: super-blocks of SB x SB tiles; work-list chunk per XCD
 
 struct GramArgs {
     const int8_t* PA;                     // [np] planes
@@ -225,6 +225,7 @@ struct GramArgs {
     int8_t* R;                            // [G][np][Dq][Dq]
     int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
     int by_neuron;                        // work lists: XCD y owns neuron y (G == 8)
+    int sb;                               // super-block edge of the clustered tile order (tiles)
     int kt0;                              // 320-tile kernel only: first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
 };
@@ -239,7 +240,7 @@ __device__ __forceinline__ int isqrt_tri_i(int t) {
 // tile t of a plane's lower triangle in CLUSTERED order: super-blocks of SB x SB tiles, row by row (boustrophedon), so that a run of
 // ~32 consecutive tiles touches few distinct 256-row strips: the workgroups of an XCD, which take such a run together, share the
 // strips through their L2 (with the plain triangular order every workgroup streamed its own two strips: 2.2 instead of 3.7 POPS)
-__device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn) {
+__device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn, const int SB = 6) {
     const int nsb = (ntm + SB - 1) / SB;
     for (int I = 0; I < nsb; ++I) {
         const int r0 = I * SB, nr = min(SB, ntm - r0);
@@ -504,6 +505,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
                     asm volatile("" ::: "memory");
                 }
                 // requests of tile kt + BNST - 1: two per row in rows 4..8
+                // (measured alternatives, same box, ms per launch: rows 5..9 106.7, all ten in rows 4 and 5 102.1, this 100.1-102.0)
                 if constexpr (I >= 4 && I <= 8 && (J == 3 || J == 7)) dma_piece(dst, 2 * (I - 4) + (J == 7));
                 // B fragments of the next tile: fragment J-1 one MFMA after its last use (row 9); fragment 9 below
                 if constexpr (I == 9 && J >= 1) FB[J - 1] = rdB(nxt, J - 1);
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
             }
             if (w >= 0) {
                 int tm, tn;
-                clustered_tile(w % ntiles, ntm, tm, tn);
+                clustered_tile(w % ntiles, ntm, tm, tn, g.sb);
                 ticket[1] = w / ntiles; ticket[2] = tm; ticket[3] = tn;
             }
             ticket[0] = w;
@@ -722,7 +724,8 @@ int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, i
     const int nkt = (int)(Kp / BKB);
     for (int kt0 = 0; kt0 < (big ? nkt : 1); kt0 += KCH) {
         static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();   // A/B switch: "chunk"
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, kt0, pgl_sched_slot(st)};
+        // super-blocks of 6 x 6 tiles (measured on one box, ms per launch: 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, kt0, pgl_sched_slot(st)};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         if (big && big_stages == 4) hipLaunchKernelGGL((i8_gram_kernel<true, 4>), dim3(grid), dim3(256), 4 * BSTAGE, st, g);
         else if (big) hipLaunchKernelGGL((i8_gram_kernel<true, 3>), dim3(grid), dim3(256), 3 * BSTAGE, st, g);

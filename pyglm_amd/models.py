@@ -146,6 +146,9 @@ class NonlinearAutoregressiveModel(object):
         nccl = dist.get_backend() == "nccl"
         counts = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
         maxc = max(hi - lo for lo, hi in counts)
+        was_bool = arr.dtype == np.bool_
+        if was_bool:
+            arr = arr.astype(np.uint8)           # (bytes travel; not every collective backend takes bool tensors)
         pad = np.zeros((maxc,) + arr.shape[1:], dtype=arr.dtype)
         pad[:arr.shape[0]] = arr
         t = torch.from_numpy(np.ascontiguousarray(pad))
@@ -154,6 +157,8 @@ class NonlinearAutoregressiveModel(object):
         outs = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(outs, t)
         out = np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(outs, counts)], axis=0)
+        if was_bool:
+            out = out.astype(bool)
         self.comm_seconds += time.perf_counter() - t0
         return out
 
