@@ -149,16 +149,17 @@ struct PlaneArgs {
 //     q = rint(v / p) by the add-and-subtract of M = 1.5 2^52,     r = v - p q  (one fma, exact),
 // |r| <= p/2 + 0.4 < 128: a valid signed-byte representative (not always the smallest one; the GEMM and the CRT only need congruence).
 // The fma is taken on v + M, so the byte is the low byte of the result's mantissa: no conversion instruction, no integer division.
-constexpr int PT_D = 16, PT_T = 256;
+constexpr int PT_D = 16;
 constexpr double MAGIC = 6755399441055744.0;      // 1.5 * 2^52
-__global__ __launch_bounds__(256) void i8_planes_kernel(PlaneArgs a, int G) {
+template <int PT_T>                                // time bins (= threads) per workgroup: one K tile of 64 bins per wave
+__global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
     __shared__ double tile[PT_D][PT_T + 1];
     __shared__ double oms[PT_T];
     const int t0 = blockIdx.x * PT_T, d0 = blockIdx.y * PT_D;
     const int tid = threadIdx.x;
     {
         const int dl = tid & (PT_D - 1), d = d0 + dl;
-        for (int tl = tid / PT_D; tl < PT_T; tl += 256 / PT_D) {
+        for (int tl = tid / PT_D; tl < PT_T; tl += PT_T / PT_D) {
             const int t = t0 + tl;
             tile[dl][tl] = (t < a.T && d < a.D) ? a.X[(long)t * a.ldx + d] : 0.0;
         }
@@ -226,6 +227,7 @@ struct GramArgs {
     int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
     int by_neuron;                        // work lists: XCD y owns neuron y (G == 8)
     int sb;                               // super-block edge of the clustered tile order (tiles)
+    int idle_wave;                        // 320-tile kernel: the wave above the diagonal of a diagonal tile idles
     int kt0;                              // 320-tile kernel only: first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
 };
@@ -408,14 +410,16 @@ __device__ __forceinline__ void big_mfma(v4i& acc, const v4i& a, const v4i& b) {
     else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-template <int I, int J, typename F>
+// TRI: the wave tile straddles the diagonal (a diagonal wave of a diagonal tile): the 16 x 16 blocks strictly above it (J > I) are
+// never read, so their MFMAs are not issued (45 of 100); the slots keep their places
+template <bool TRI, int I, int J, typename F>
 __device__ __forceinline__ void big_rows(v4i (&acc)[10][10], v4i (&FA)[5], v4i (&FB)[10], F&& slot) {
     if constexpr (I < 10) {
-        big_mfma<I * 10 + J>(acc[I][J], FA[I % 5], FB[J]);
+        if constexpr (!TRI || J <= I) big_mfma<I * 10 + J>(acc[I][J], FA[I % 5], FB[J]);
         slot(std::integral_constant<int, I>{}, std::integral_constant<int, J>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (J == 9) big_rows<I + 1, 0>(acc, FA, FB, slot);
-        else big_rows<I, J + 1>(acc, FA, FB, slot);
+        if constexpr (J == 9) big_rows<TRI, I + 1, 0>(acc, FA, FB, slot);
+        else big_rows<TRI, I, J + 1>(acc, FA, FB, slot);
     }
 }
 
@@ -462,11 +466,6 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(sb[i] + voff), (lds_ptr_t)(lds + stage * BSTAGE + (wv + 4 * i) * 1024), 16, 0, 0);
             sb[i] += gadv;
         };
-        v4i acc[10][10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-#pragma unroll
-            for (int j = 0; j < 10; ++j) acc[i][j] = v4i{0, 0, 0, 0};
         // prologue: tiles 0 .. BNST-2 of the pass
 #pragma unroll
         for (int i = 0; i < 10; ++i) dma_piece(0, i);
@@ -481,18 +480,45 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
         } else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // On a diagonal tile the wave that owns rows 0..159 x columns 160..319 lies wholly above the diagonal and nothing ever reads its
+        // residues: it keeps its share of the requests and the barriers and issues no MFMA, no fragment read and no store (under the
+        // power limit what an idle SIMD does not burn is clock for the other three: 3 % of the launch's MFMA energy)
+        if (g.idle_wave && tm == tn && wv == 1) {
+            int cur = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int dst = cur == 0 ? BNST - 1 : cur - 1;
+                if (kt + BNST >= nk) gadv = 0;
+                if constexpr (BNST == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 10; ++i) dma_piece(dst, i);
+                cur = cur == BNST - 1 ? 0 : cur + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            return;
+        }
+        v4i acc[10][10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[i][j] = v4i{0, 0, 0, 0};
         v4i FA[5], FB[10];
 #pragma unroll
         for (int f = 0; f < 10; ++f) FB[f] = rdB(0, f);
         FA[0] = rdA(0, 0);
         FA[1] = rdA(0, 1);
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // accumulator initialisation (VALU writes) ahead of the first MFMA
+        auto k_loop = [&](auto tri_c) {
+        constexpr bool TRI = decltype(tri_c)::value;
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             const int nxt = cur == BNST - 1 ? 0 : cur + 1;
             const int dst = cur == 0 ? BNST - 1 : cur - 1;           // the stage of tile kt-1 takes tile kt + BNST - 1
             if (kt + BNST >= nk) gadv = 0;
-            big_rows<0, 0>(acc, FA, FB, [&](auto ic, auto jc) {
+            big_rows<TRI, 0, 0>(acc, FA, FB, [&](auto ic, auto jc) {
                 constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
                 // A fragment of row I+2 (rows 10, 11 = rows 0, 1 of the next tile), two rows ahead; five register sets in rotation
                 // (10 rows = 2 x 5: the rotation comes back to set 0 at every tile)
@@ -513,6 +539,9 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
             FB[9] = rdB(nxt, 9);
             cur = nxt;
         }
+        };
+        if (tm == tn && g.idle_wave && wm == wn) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // last (redundant) requests landed; MFMA results readable
         __builtin_amdgcn_s_barrier();                      // every wave is done with the stages before the next item refills them
         auto store = [&](auto accum_c) {
@@ -698,7 +727,10 @@ int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     PlaneArgs a{X, ldx, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
-    hipLaunchKernelGGL(i8_planes_kernel, dim3((unsigned)((Kp + PT_T - 1) / PT_T), Dq / PT_D), dim3(256), 0, st, a, G);
+    static const int pt = [] { const char* e = getenv("PGL_I8_PLANES_T"); const int v = e ? atoi(e) : 0; return (v == 512 || v == 128) ? v : 256; }();   // A/B switch
+    if (pt == 512) hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
+    else if (pt == 128) hipLaunchKernelGGL(i8_planes_kernel<128>, dim3((unsigned)((Kp + 127) / 128), Dq / PT_D), dim3(128), 0, st, a, G);
+    else hipLaunchKernelGGL(i8_planes_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
@@ -725,7 +757,8 @@ int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, i
     for (int kt0 = 0; kt0 < (big ? nkt : 1); kt0 += KCH) {
         static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();   // A/B switch: "chunk"
         // super-blocks of 6 x 6 tiles (measured on one box, ms per launch: 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, kt0, pgl_sched_slot(st)};
+        static const bool idle_off = [] { const char* e = getenv("PGL_I8_IDLE"); return e && e[0] == '0'; }();                  // A/B switch
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, idle_off ? 0 : 1, kt0, pgl_sched_slot(st)};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         if (big && big_stages == 4) hipLaunchKernelGGL((i8_gram_kernel<true, 4>), dim3(grid), dim3(256), 4 * BSTAGE, st, g);
         else if (big) hipLaunchKernelGGL((i8_gram_kernel<true, 3>), dim3(grid), dim3(256), 3 * BSTAGE, st, g);
