@@ -727,10 +727,8 @@ int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     PlaneArgs a{X, ldx, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
-    static const int pt = [] { const char* e = getenv("PGL_I8_PLANES_T"); const int v = e ? atoi(e) : 0; return (v == 512 || v == 128) ? v : 256; }();   // A/B switch
-    if (pt == 512) hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
-    else if (pt == 128) hipLaunchKernelGGL(i8_planes_kernel<128>, dim3((unsigned)((Kp + 127) / 128), Dq / PT_D), dim3(128), 0, st, a, G);
-    else hipLaunchKernelGGL(i8_planes_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
+    // 256 time bins per workgroup (measured on one box, ms per group of 8: 128 bins 16.0, 256 15.0-15.2, 512 15.3)
+    hipLaunchKernelGGL(i8_planes_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
