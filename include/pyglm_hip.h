@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 3
+#define PGL_ABI_VERSION 4
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -112,7 +112,9 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
  * The same nplanes must be used for the scales, both plane sets, the product and the reconstruction. */
 int pgl_i8_max_planes(void);                     /* 15 */
 int pgl_i8_padded_rows(int D);                   /* Dq */
-int pgl_i8_min_planes(int T);                    /* fewest moduli with norm bits >= 50 (error at the fp64 product's level): 13 */
+int pgl_i8_min_planes(int T);                    /* fewest moduli with norm bits >= 50 (error below the reference's own dgemm): 13 */
+int pgl_i8_auto_planes(int T);                   /* fewest moduli (>= 12) whose rounding error stays at or below 3/4 of the fp64 MFMA Gram kernel's
+                                                  * own, measured as rms 1.39e-17 sqrt(T) |a_i||b_j|: 12 for T >= 87 000, 13 down to T = 410, then 14 */
 int pgl_i8_norm_bits(int nplanes, int T);        /* floor(log2(pgl_i8_norm_limit)) */
 double pgl_i8_norm_limit(int nplanes, int T);    /* norm of the integer columns */
 size_t pgl_i8_plane_bytes(int D, int T);
@@ -196,6 +198,7 @@ typedef struct {
     double* llpart;                /* [pgl_pg_loglik_partials(T)][nloc] scratch */
     uint64_t elem0;                /* PG stream element of the first bin: sum of T of the data sets before this one */
     int int8;                      /* 1: likelihood Gram on the integer matrix cores (sA, PA valid); 0: fp64 MFMA kernel */
+    int planes;                    /* moduli of this data set's planes (0: pgl_sweep_t.planes) */
     const double* sA;              /* [D] column scales of X (pgl_i8_scales) */
     const void* PA;                /* residue planes of X (pgl_i8_planes), `planes` of them */
     const double* omega_override;  /* optional [T][nloc]: replaces the PG draws (test hook: the reference fixtures inject omega) */
@@ -213,7 +216,7 @@ typedef struct {
     int N, B, n0, nloc, nb;        /* neurons, basis functions, first local neuron (global index), local neurons, neurons per batch */
     int obs; double xi;            /* 0 Bernoulli, 1 negative binomial (b = y + xi), 2 Gaussian */
     int visit_order;               /* 1: sweep tableau in proposal order (see pgl_flip_t) */
-    int planes, i8_group;          /* integer Gram: moduli in use, neurons per launch (<= 8) */
+    int planes, i8_group;          /* integer Gram: moduli in use where a data set does not say, neurons per launch (<= 8) */
     const pgl_dataset_t* datasets; int ndatasets;      /* host array */
     int* a; double* W; double* b;  /* chain state, in/out: [nloc][N] (0/1), [nloc][D] (zeros where a = 0), [nloc] */
     const double* rho;             /* [nloc][N] */

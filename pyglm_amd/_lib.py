@@ -24,7 +24,7 @@ class CholState(ctypes.Structure):   # pgl_chol_t
 
 class Dataset(ctypes.Structure):     # pgl_dataset_t
     _fields_ = [("T", c_i), ("Tp", c_i), ("X", c_p), ("Xt", c_p), ("Y", c_p), ("Psi", c_p), ("OK", c_p), ("llpart", c_p), ("elem0", c_u64),
-                ("int8", c_i), ("sA", c_p), ("PA", c_p), ("omega_override", c_p)]
+                ("int8", c_i), ("planes", c_i), ("sA", c_p), ("PA", c_p), ("omega_override", c_p)]
 
 
 NSTAGES = 16
@@ -65,6 +65,7 @@ SIGNATURES = {
     "pgl_i8_max_planes": [],
     "pgl_i8_padded_rows": [c_i],
     "pgl_i8_min_planes": [c_i],
+    "pgl_i8_auto_planes": [c_i],
     "pgl_i8_norm_bits": [c_i, c_i],
     "pgl_i8_norm_limit": [c_i, c_i],
     "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
@@ -90,7 +91,7 @@ SIGNATURES = {
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

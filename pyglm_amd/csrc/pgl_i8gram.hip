@@ -694,6 +694,21 @@ int pgl_k_i8_min_planes(int T) {
     return NP + 1;
 }
 
+// How many moduli by default: the fewest (from 12) whose operand-rounding error, sqrt(2/12) / min(limit, 2^50) relative to |a_i||b_j|, stays
+// at or below 3/4 of the error of the kernel this path replaces -- the fp64 MFMA Gram, which accumulates T/4 steps in sequence and was
+// measured at rms 1.39e-17 sqrt(T) |a_i||b_j| on the bench's data (profiles/r02_f64_kernel_error.md: 4.4e-15 at T = 1e5, 2.2e-15 at 2e4).
+// 12 for T >= 87 000 (3.1e-15), 13 down to T = 410 (2.1e-16), 14 below.  tests/test_gpu_i8gram.py measures both sides on the device.
+int pgl_k_i8_auto_planes(int T) {
+    const double e64 = 1.39e-17 * std::sqrt((double)(T < 1 ? 1 : T));
+    for (int k = 12; k <= NP; ++k) {
+        const double lim = pgl_k_i8_norm_limit(k, T);
+        if (!(lim >= 256.0)) continue;
+        const double cap = std::ldexp(1.0, ELEM_BITS);
+        if (std::sqrt(2.0 / 12.0) / (lim < cap ? lim : cap) <= 0.75 * e64) return k;
+    }
+    return NP;
+}
+
 size_t pgl_k_i8_plane_bytes(int D, int T) {
     const long Dq = pgl_k_i8_padded_rows(D), Kp = pgl_i8_kp(T);
     return (size_t)NP * Dq * Kp;

@@ -141,10 +141,10 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
         PGL_CHECK_ARG(d.T > 0 && d.Tp >= d.T && d.Tp % 16 == 0 && d.X && d.Xt && d.Y && d.Psi && d.OK && d.llpart);
-        PGL_CHECK_ARG(!d.int8 || (d.sA && d.PA));
+        PGL_CHECK_ARG(!d.int8 || (d.sA && d.PA && (d.planes > 0 || s->planes > 0)));
         any_i8 = any_i8 || d.int8;
     }
-    PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= 8 && s->planes >= 1 && s->obs != 2));
+    PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= 8 && s->obs != 2));
     Clock clk{s->times, st};
 
     // ---- activation of the whole shard, PG draw / kappa / log-likelihood (regression.py:195-201, 491-511)
@@ -208,7 +208,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     clk.toc(m);
                     continue;
                 }
-                const int G = s->i8_group, np = s->planes;
+                const int G = s->i8_group, np = d.planes > 0 ? d.planes : s->planes;
                 double* amax = s->i8_stat;
                 double* ss = s->i8_stat + (long)G * D;
                 double* sB = s->i8_stat + 2L * G * D;

@@ -127,10 +127,12 @@ class GibbsEngine(object):
         import os
         self.gram = gram or os.environ.get("PGL_GRAM", "auto")
         assert self.gram in ("auto", "fp64", "int8")
-        # number of residue planes (moduli) of the integer path: 13 keeps the operand rounding at the fp64 product's own level (column
-        # norms >= 2^49), every further plane buys 4 more bits; None / PGL_I8_PLANES unset = I8_PLANES
-        self.planes = int(planes or os.environ.get("PGL_I8_PLANES", self.I8_PLANES))
-        assert 1 <= self.planes <= _lib.load().pgl_i8_max_planes()
+        # number of residue planes (moduli) of the integer path: an int, or None / PGL_I8_PLANES unset = per data set the fewest whose
+        # rounding error stays below the fp64 kernel's own measured error (pgl_i8_auto_planes: 12 for T >= 87 000, else 13 / 14); 13 keeps
+        # it below the reference's CPU dgemm at any T; every further plane buys 4 more bits
+        planes = planes or os.environ.get("PGL_I8_PLANES")
+        self.planes = int(planes) if planes else None
+        assert self.planes is None or 1 <= self.planes <= _lib.load().pgl_i8_max_planes()
         self._i8_scratch = None
         per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
         if batch is None:
@@ -284,15 +286,16 @@ class GibbsEngine(object):
         if ds.int8:
             # residue planes of X (once per data set), scaled column by column from the columns' norms and maxima
             lib = _lib.load()
-            if lib.pgl_i8_norm_bits(self.planes, T) < 8:
-                raise ValueError("%d residue planes cannot hold T = %d time bins" % (self.planes, T))
+            ds.planes = self.planes or lib.pgl_i8_auto_planes(T)
+            if lib.pgl_i8_norm_bits(ds.planes, T) < 8:
+                raise ValueError("%d residue planes cannot hold T = %d time bins" % (ds.planes, T))
             stat = self._z(2, self.D)
             ds.sA = self._z(self.D)
             call("pgl_i8_colstats", ptr(ds.X), self.Dp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
-            call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, self.planes, ptr(ds.sA), st)
-            ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * self.planes, dtype=torch.int8, device=self.dev)
-            call("pgl_i8_planes", ptr(ds.X), self.Dp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, self.planes, st)
-            self._i8_reserve(T)
+            call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, ds.planes, ptr(ds.sA), st)
+            ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
+            call("pgl_i8_planes", ptr(ds.X), self.Dp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
+            self._i8_reserve(T, ds.planes)
             torch.cuda.synchronize(self.dev)
         if self.obs == 2:
             ones = self._z(ds.Tp, 2)
@@ -304,12 +307,16 @@ class GibbsEngine(object):
 
     # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
     I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
-    I8_PLANES = 13        # default number of moduli (see __init__; DESIGN.md section 8c has the measured error levels)
     I8_MIN_D, I8_MIN_T = 1024, 2048
 
-    def _i8_need(self, T, G):
+    @staticmethod
+    def _lib_auto(T):
+        return _lib.load().pgl_i8_auto_planes(int(T))
+
+    def _i8_need(self, T, G, planes=None):
         lib = _lib.load()
-        return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D)) // lib.pgl_i8_max_planes() * self.planes
+        planes = planes or self.planes or lib.pgl_i8_auto_planes(T)
+        return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D)) // lib.pgl_i8_max_planes() * planes
 
     def _use_int8(self, T):
         """the Gram of a data set goes through the int8 MFMA if asked for, or (auto) if the shape is one where it is faster than the fp64
@@ -329,21 +336,20 @@ class GibbsEngine(object):
                           "Gram runs on the fp64 MFMA kernel" % (self.D, T, free / 1e9, self.dev), RuntimeWarning, stacklevel=3)
         return fits
 
-    def _i8_reserve(self, T):
-        """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the longest data set seen so far"""
+    def _i8_reserve(self, T, planes):
+        """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the largest data set seen so far"""
         lib = _lib.load()
         import os
-        have = self._i8_scratch[0] if self._i8_scratch else 0
-        if have >= self._i8_need(T, 1) and self._i8_scratch[1] >= T:
+        if self._i8_scratch and self._i8_scratch[0] >= self._i8_need(T, self._i8_scratch[2], planes):
             return
         self._i8_scratch = None
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info(self.dev)
-        G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // self._i8_need(T, 1))))
+        G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // self._i8_need(T, 1, planes))))
         mp = lib.pgl_i8_max_planes()
-        self._i8_scratch = (self._i8_need(T, G), T, G,
-                            torch.empty(G * lib.pgl_i8_plane_bytes(self.D, T) // mp * self.planes, dtype=torch.int8, device=self.dev),
-                            torch.empty(G * lib.pgl_i8_residue_bytes(self.D) // mp * self.planes, dtype=torch.int8, device=self.dev),
+        self._i8_scratch = (self._i8_need(T, G, planes), T, G,
+                            torch.empty(G * lib.pgl_i8_plane_bytes(self.D, T) // mp * planes, dtype=torch.int8, device=self.dev),
+                            torch.empty(G * lib.pgl_i8_residue_bytes(self.D) // mp * planes, dtype=torch.int8, device=self.dev),
                             self._z(3, G, self.D))          # per group: column maxima, sums of squares, scales of omega_g X
 
     @_on_device
@@ -467,12 +473,12 @@ class GibbsEngine(object):
                 ov = torch.from_numpy(np.ascontiguousarray(omega_override[i], dtype=np.float64).reshape(ds.T, nloc)).to(self.dev)
                 keep.append(ov)
             dsets[i] = _lib.Dataset(ds.T, ds.Tp, ptr(ds.X), ptr(ds.Xt), ptr(ds.Y), ptr(ds.Psi), ptr(ds.OK), ptr(ds.llpart), ds.elem0, int(ds.int8),
-                                    ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)), ptr(ov))
+                                    int(getattr(ds, "planes", 0) or 0), ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)), ptr(ov))
         i8 = self._i8_scratch
         if self.profile and self._times is None:
             self._times = _lib.StageTimes()
         n_act = int(a.sum(axis=1).max()) if a.size else 0
-        sw = _lib.Sweep(N, B, self.n0, nloc, self.nb, self.obs, self.xi, int(self.visit_order), self.planes, i8[2] if i8 else 0,
+        sw = _lib.Sweep(N, B, self.n0, nloc, self.nb, self.obs, self.xi, int(self.visit_order), self.planes or 0, i8[2] if i8 else 0,
                         dsets, len(self.datasets), ptr(self.a_dev), ptr(self.W_dev), ptr(self.b_dev),
                         ptr(dev["rho"]), ptr(dev["Jw"]), ptr(dev["hw"]), ptr(dev["label"]), ptr(dev["Jb"]), ptr(dev["hb"]), ptr(dev["c0"]),
                         ptr(dev["perm"]), ptr(dev["u"]), ptr(dev["z"]), ptr(getattr(self, "inv_eta", None)), ptr(getattr(self, "G0", None)),
@@ -527,7 +533,7 @@ class GibbsEngine(object):
         st = self._st()
         _, _, G, PB, R, stat = self._i8_scratch
         assert gz <= G
-        npl = self.planes
+        npl = ds.planes
         call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
         call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)

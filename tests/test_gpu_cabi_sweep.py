@@ -50,7 +50,7 @@ def test_golden_model_sweep_through_the_c_abi_alone(golden, batch, timed):
     Yd[:, :nloc] = S
     om = up(g["M_omegas"].T)                              # (T, nloc): the omega the reference consumed
     Psi, OK, llpart = z(T, ldn), z(Tp, 2 * ldn), z(lib.pgl_pg_loglik_partials(T), nloc)        # (named: raw pointers do not keep them alive)
-    ds = (_lib.Dataset * 1)(_lib.Dataset(T, Tp, ptr(X), ptr(Xt), ptr(Yd), ptr(Psi), ptr(OK), ptr(llpart), 0, 0, None, None, ptr(om)))
+    ds = (_lib.Dataset * 1)(_lib.Dataset(T, Tp, ptr(X), ptr(Xt), ptr(Yd), ptr(Psi), ptr(OK), ptr(llpart), 0, 0, 0, None, None, ptr(om)))
     # chain state and the sweep's inputs
     a, W, b = up(g["M_A0"], np.int32), up(g["M_W0"].reshape(N, D)), up(g["M_b0"])
     S_w = np.tile(10.0 * np.eye(B), (N, N, 1, 1))

@@ -77,6 +77,7 @@ def test_norm_bits_and_minimum_planes():
             assert lib.pgl_i8_norm_bits(k, T) == _nu(k, T) and abs(lib.pgl_i8_norm_limit(k, T) / _limit(k, T) - 1) < 1e-12
     assert [lib.pgl_i8_norm_bits(k, 100000) for k in (12, 13, 14, 15)] == [46, 50, 54, 58]
     assert lib.pgl_i8_min_planes(100000) == 13 and lib.pgl_i8_min_planes(50) == 13
+    assert [lib.pgl_i8_auto_planes(T) for T in (300, 2048, 20000, 86000, 100000, 200000)] == [14, 13, 13, 13, 12, 12]
 
 
 @pytest.mark.parametrize("k", [13, 15])
@@ -198,8 +199,8 @@ def test_heavy_tailed_columns_keep_the_error_at_the_fp64_level():
     Om = 0.25 * rng.gamma(4.0, 0.25, size=(T, 4))
     Om[4321, 1] = 4e6                                            # a spike in one neuron's omega
     eng = GibbsEngine(N, B, 0, 4, batch=4, gram="int8")
-    assert eng.planes == 13
     ds = eng.add_data((rng.random((T, N)) < 0.1).astype(float), X=X)
+    assert eng.planes is None and ds.planes == 13           # auto: 13 moduli at T = 6000
     W = torch.zeros(ds.Tp, 4, dtype=torch.float64, device="cuda")
     W[:T] = torch.from_numpy(Om).cuda()
     J8 = torch.zeros(4, eng.ldj, eng.ldj, dtype=torch.float64, device="cuda")
@@ -216,6 +217,44 @@ def test_heavy_tailed_columns_keep_the_error_at_the_fp64_level():
         e_int = float(np.max((np.abs(J8[g, :D, :D].cpu().numpy() - ref) / den)[low]))
         e_f64 = float(np.max((np.abs(J64[g, :D, :D].cpu().numpy() - ref) / den)[low]))
         assert e_int < 5e-15 and e_int < 3 * max(e_f64, 1.2e-15), (g, e_int, e_f64)
+
+
+@pytest.mark.parametrize("T,want", [(100000, 12), (20000, 13)])
+def test_default_number_of_planes_stays_below_the_fp64_kernels_own_error(T, want):
+    """the rule behind the default number of moduli (pgl_i8_auto_planes), checked where it is applied: on the bench's kind of data
+    (basis-filtered Bernoulli spikes, omega ~ PG(1, psi)) the integer Gram with the automatically chosen K must not be less accurate
+    than the fp64 MFMA kernel it replaces -- both measured against the 15-plane integer Gram (error ~1e-18), relative to |a_i||b_j|"""
+    import torch
+    from pyglm_amd.engine import GibbsEngine
+    from pyglm_amd.utils.basis import cosine_basis
+    N, B, nl = 64, 5, 4
+    rng = np.random.default_rng(T)
+    Y = (rng.random((T, N)) < 0.08).astype(float)
+    W = rng.standard_normal((nl, N, B)) * 0.1
+    res = {}
+    for name, kw in (("auto", dict(gram="int8")), ("k15", dict(gram="int8", planes=15)), ("fp64", dict(gram="fp64"))):
+        eng = GibbsEngine(N, B, 0, nl, batch=nl, **kw)
+        ds = eng.add_data(Y, basis=cosine_basis(B, L=100) / 100)
+        if name == "auto":
+            assert ds.planes == want == eng._lib_auto(T)
+        eng._upload_weights(np.ones((nl, N), bool), W, np.full(nl, -2.0))
+        with torch.cuda.device(eng.dev):
+            eng._psi_pass(True, 3, 0)
+            eng._gram(0, nl, 0)
+            torch.cuda.synchronize()
+        D = N * B
+        res[name] = eng.Jslots[0][:nl, :D, :D].cpu().numpy()
+        X, Om = ds.X[:T, :D].cpu().numpy(), ds.OK[:T, :nl].cpu().numpy()
+        del eng, ds
+        torch.cuda.empty_cache()
+    low = np.tril(np.ones((D, D), bool))
+    na = np.sqrt((X * X).sum(0))
+    for g in range(nl):
+        den = np.outer(na, np.sqrt(((Om[:, g:g + 1] * X) ** 2).sum(0)))
+        e_int = (np.abs(res["auto"][g] - res["k15"][g]) / den)[low]
+        e_f64 = (np.abs(res["fp64"][g] - res["k15"][g]) / den)[low]
+        assert np.sqrt((e_int ** 2).mean()) <= np.sqrt((e_f64 ** 2).mean()), (g, np.sqrt((e_int ** 2).mean()), np.sqrt((e_f64 ** 2).mean()))
+        assert e_int.max() <= e_f64.max(), (g, e_int.max(), e_f64.max())
 
 
 @pytest.mark.parametrize("N,B,T,batch", [(60, 3, 1500, 16), (110, 4, 2500, None)])
