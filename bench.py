@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--gram", default="auto", choices=["auto", "fp64", "int8"],
                     help="likelihood Gram: auto (the engine's default: exact integer arithmetic on the int8 MFMA where that is faster, DESIGN.md "
                          "section 8c), or forced onto the fp64 MFMA kernel / the int8 path")
-    ap.add_argument("--planes", type=int, default=None, help="residue planes (moduli) of the integer Gram (default: the engine's choice per data set, pgl_i8_auto_planes)")
+    ap.add_argument("--planes", type=int, default=None, help="residue planes (moduli) of the integer Gram (default: the engine's, 13)")
     ap.add_argument("--no-fp64-compare", action="store_true",
                     help="skip the extra sweeps (untimed for `value`) that fill int8_vs_fp64 and fp64_gram_path")
     ap.add_argument("--fp64-steps", type=int, default=3, help="sweeps timed with the Gram on the fp64-MFMA kernel for fp64_gram_path")

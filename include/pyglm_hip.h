@@ -91,14 +91,14 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
 
 /* ---- the same weighted Gram on the INTEGER matrix cores -------------------------------------------
  * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to integers
- *     A[t][i] = rint(x_ti sA_i),   B_g[t][j] = rint((omega_gt x_tj) sB_gj),
+ *     A[t][i] = rint(x_ti sA_i),   B_g[t][j] = rint((omega_gt x_tj) sB_gj),      sA, sB powers of two,
  * one int8 GEMM per modulus for the first `nplanes` of 15 pairwise coprime moduli <= 256 (256, 255, 253, 251, 247, 241, 239, 233, 229,
  * 227, 223, 217, 211, 199, 197), int32 accumulation (re-reduced every 128 000 bins), exact Chinese-remainder reconstruction,
  * J_ij = (S_ij / sA_i) / sB_gj.  The scales are set from each column's Euclidean norm and largest element so that the integer columns have
- * norm pgl_i8_norm_limit(nplanes, T) (2^46.9 / 2^50.8 / 2^54.6 / 2^58.4 for 12 / 13 / 14 / 15 moduli; pgl_i8_norm_bits = floor(log2)) unless
- * their largest element would reach 2^50; Cauchy-Schwarz then keeps every |S_ij| inside the CRT range for any data, and the rounding
- * error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_gj|^-2) / 12) |a_i||b_gj| (2.1e-16 |a_i||b_gj| at 13 moduli): pinned to the
- * column norms.
+ * norms in (limit / 2, limit], limit = pgl_i8_norm_limit(nplanes, T) (2^46.9 / 2^50.8 / 2^54.6 / 2^58.4 for 12 / 13 / 14 / 15 moduli;
+ * pgl_i8_norm_bits = floor(log2)) unless their largest element would reach 2^50; Cauchy-Schwarz then keeps every |S_ij| inside the CRT
+ * range for any data, and with independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_gj|^-2) / 12)
+ * |a_i||b_gj| (2-4e-16 |a_i||b_gj| at 13 moduli; a few times that where a column repeats few distinct values): pinned to the column norms.
  *   pgl_i8_colstats amax[g][c] = max_t |v_tc|, sumsq[g][c] = sum_t v_tc^2 with v = X (Om = NULL, G = 1) or Om[:, g] * X, G <= 8; one pass
  *                   over X, deterministic (fixed summation order)
  *   pgl_i8_scales   scale[k] from (amax[k], sumsq[k]) for ncols = G * D columns (1 for an empty column, NaN for a non-finite one)
@@ -112,9 +112,7 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
  * The same nplanes must be used for the scales, both plane sets, the product and the reconstruction. */
 int pgl_i8_max_planes(void);                     /* 15 */
 int pgl_i8_padded_rows(int D);                   /* Dq */
-int pgl_i8_min_planes(int T);                    /* fewest moduli with norm bits >= 50 (error below the reference's own dgemm): 13 */
-int pgl_i8_auto_planes(int T);                   /* fewest moduli (>= 12) whose rounding error stays at or below 3/4 of the fp64 MFMA Gram kernel's
-                                                  * own, measured as rms 1.39e-17 sqrt(T) |a_i||b_j|: 12 for T >= 87 000, 13 down to T = 410, then 14 */
+int pgl_i8_min_planes(int T);                    /* fewest moduli with norm bits >= 50: 13 (the engine's default) */
 int pgl_i8_norm_bits(int nplanes, int T);        /* floor(log2(pgl_i8_norm_limit)) */
 double pgl_i8_norm_limit(int nplanes, int T);    /* norm of the integer columns */
 size_t pgl_i8_plane_bytes(int D, int T);

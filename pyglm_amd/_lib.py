@@ -65,7 +65,6 @@ SIGNATURES = {
     "pgl_i8_max_planes": [],
     "pgl_i8_padded_rows": [c_i],
     "pgl_i8_min_planes": [c_i],
-    "pgl_i8_auto_planes": [c_i],
     "pgl_i8_norm_bits": [c_i, c_i],
     "pgl_i8_norm_limit": [c_i, c_i],
     "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],

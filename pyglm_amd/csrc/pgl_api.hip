@@ -148,7 +148,6 @@ size_t pgl_i8_residue_bytes(int D) { return pgl_k_i8_residue_bytes(D); }
 int pgl_i8_max_planes(void) { return pgl_k_i8_max_planes(); }
 int pgl_i8_padded_rows(int D) { return pgl_k_i8_padded_rows(D); }
 int pgl_i8_min_planes(int T) { return pgl_k_i8_min_planes(T); }
-int pgl_i8_auto_planes(int T) { return pgl_k_i8_auto_planes(T); }
 int pgl_i8_norm_bits(int nplanes, int T) { return pgl_k_i8_nu(nplanes, T); }
 double pgl_i8_norm_limit(int nplanes, int T) { return pgl_k_i8_norm_limit(nplanes, T); }
 #define PGL_CHECK_PLANES(np, T) PGL_CHECK_ARG((np) >= 1 && (np) <= pgl_k_i8_max_planes() && pgl_k_i8_nu((np), (T)) >= 8)

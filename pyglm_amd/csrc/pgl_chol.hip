@@ -39,17 +39,38 @@ __global__ __launch_bounds__(256) void active_index_kernel(CholArgs g) {
     g.na[n] = cnt;
 }
 
+// Ac[i][j] = J_sym[act[i]][act[j]] for j >= i (upper triangle only: nothing downstream reads below the diagonal of Ac), hc[i] = h[act[i]].
+// J stores its lower triangle, so entry (act[i], act[j]), j >= i, lives in ROW act[j]: a 64 x 64 tile is read along i (the columns act[i]
+// of a stored row ascend, in runs of B) and turned in LDS so that Ac is written along j.  (One thread per element with the row index in
+// blockIdx.y read the stored rows column-wise and launched 18 million workgroups per batch at cfg3: 16 ms; this is 3.)
 __global__ __launch_bounds__(256) void gather_active_kernel(CholArgs g) {
     const int n = blockIdx.z;
     const int na = g.na[n];
-    const int i = blockIdx.y;                       // compact row
-    const int j = blockIdx.x * 256 + threadIdx.x;   // compact col
-    if (i >= na || j >= na || j < i) return;        // upper triangle only: nothing downstream reads below the diagonal of Ac
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    if (i0 >= na || j0 >= na || j0 + 63 < i0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double t[64][65];
+    __shared__ int ai[64], aj[64];
     const int* act = g.act + (long)n * g.ldact;
-    const int gi = act[i], gj = act[j];
+    if (threadIdx.x < 64) ai[threadIdx.x] = i0 + threadIdx.x < na ? act[i0 + threadIdx.x] : -1;
+    else if (threadIdx.x < 128) aj[threadIdx.x - 64] = j0 + threadIdx.x - 64 < na ? act[j0 + threadIdx.x - 64] : -1;
+    __syncthreads();
     const double* J = g.J + (long)n * g.strideJ;
-    g.Ac[(long)n * g.strideC + (long)i * g.ldc + j] = gi >= gj ? J[(long)gi * g.ldj + gj] : J[(long)gj * g.ldj + gi];
-    if (j == i) g.hc[(long)n * g.ldc + i] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
+    const int gi = ai[lane];
+    for (int jj = wave; jj < 64; jj += 4) {
+        const int gj = aj[jj];
+        double v = 0.0;
+        if (gi >= 0 && gj >= 0) v = gj >= gi ? J[(long)gj * g.ldj + gi] : J[(long)gi * g.ldj + gj];
+        t[jj][lane] = v;
+    }
+    __syncthreads();
+    double* Ac = g.Ac + (long)n * g.strideC;
+    const int j = j0 + lane;
+    for (int ii = wave; ii < 64; ii += 4) {
+        const int i = i0 + ii;
+        if (i < na && j < na && j >= i) Ac[(long)i * g.ldc + j] = t[lane][ii];
+    }
+    if (i0 == j0 && threadIdx.x < 64 && gi >= 0) g.hc[(long)n * g.ldc + i0 + lane] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
 }
 
 // factor the 64x64 diagonal block at q0: A11 = U11' U11, U11 written to the upper triangle in place
@@ -225,7 +246,7 @@ int pgl_k_chol_index(const PglCholState& s, hipStream_t st) {
 int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     CholArgs g = mk(s);
     if (na_max <= 0) return PGL_OK;
-    hipLaunchKernelGGL(gather_active_kernel, dim3((na_max + 255) / 256, na_max, s.nb), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gather_active_kernel, dim3((na_max + 63) / 64, (na_max + 63) / 64, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
     auto trailing = [&](int krow0, int K, int c0, int mfix) -> int {
         // C[c0.., c0..] -= P' P with P = rows [krow0, krow0+K) of Ac, columns from c0 (k-major panel)

@@ -99,7 +99,6 @@ size_t pgl_k_i8_residue_bytes(int);
 int pgl_k_i8_max_planes(void);
 int pgl_k_i8_padded_rows(int);
 int pgl_k_i8_min_planes(int);
-int pgl_k_i8_auto_planes(int);
 int pgl_k_i8_nu(int, int);
 double pgl_k_i8_norm_limit(int, int);
 int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);

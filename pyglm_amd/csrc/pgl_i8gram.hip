@@ -1,15 +1,17 @@
 // The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (the engine's choice at large shapes,
 // the fp64 kernel of pgl_gemm.hip otherwise).  The fp64 operands are scaled COLUMN BY COLUMN to integers,
 //     A[t][i] = rint(x_ti sA_i),      B_n[t][j] = rint((omega_nt x_tj) sB_nj),
-// with scales chosen from each column's Euclidean norm and largest element (i8_colstats_kernel, i8_scales_kernel):
-//     |A_i|_2 = |B_nj|_2 = limit(K, T)   unless the largest element would reach 2^50 (then that bound decides),
+// with power-of-two scales chosen from each column's Euclidean norm and largest element (i8_colstats_kernel, i8_scales_kernel):
+//     |A_i|_2, |B_nj|_2 in (limit(K, T) / 2, limit(K, T)]   unless the largest element would reach 2^50 (then that bound decides),
 // so that by Cauchy-Schwarz every entry of the integer Gram S = A'B_n obeys |S_ij| <= |A_i||B_nj| < prod(p)/2 for the K <= 15 pairwise
 // coprime moduli p <= 256 in use (limit = sqrt(prod(p)/2) less the rounding slack: 2^46.9 / 2^50.8 / 2^54.6 / 2^58.4 for K = 12..15).  S is computed modulo each p -- one int8 GEMM per
 // modulus on residues that fit a signed byte, int32 accumulation (re-reduced mod p every 128 000 time bins) -- and reconstructed exactly by
 // the Chinese remainder theorem;  J_ij = S_ij / (sA_i sB_nj).  The only approximation is the rounding of the operands to integers: with
-// independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_nj|^-2) / 12) |a_i||b_nj|, i.e. 2.1e-16 |a_i||b_j|
-// at K = 13, 1.5e-17 at K = 14 for ordinary columns (a column whose norm is one outlier element is held at 2^50 by the element bound at
-// every K: 3.6e-16) -- for ANY data: the precision is pinned to the column norms, not to the column maxima.
+// independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_nj|^-2) / 12) |a_i||b_nj|, i.e. 2.1e-16 .. 4.2e-16
+// |a_i||b_j| at K = 13 (a column whose norm is one outlier element is held at 2^49..2^50 by the element bound at every K) -- for ANY
+// dynamic range: the precision is pinned to the column norms, not to the column maxima.  Roundings of REPEATED values are not independent
+// (a design matrix of filtered spikes takes few distinct values per column): measured on the bench's data the error is ~5x that model,
+// still several times below the fp64 kernel's own (tests/test_gpu_i8gram.py).
 //
 //   i8_colstats_kernel max_t |v| and sum_t v^2 per column of X (once per data set) and of omega_g X (per neuron and sweep), deterministic
 //   i8_scales_kernel   the scale of every column from those statistics
@@ -117,8 +119,11 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
     }
 }
 
-// scale[k] = min(limit / |v|_2, 2^ELEM_BITS (1 - 2^-30) / max|v|): the integer column gets the largest norm the CRT range allows
-// (`limit`, pgl_k_i8_norm_limit) unless its largest element would reach 2^50.  1 for an empty column, NaN for a non-finite one.
+// scale[k] = the largest POWER OF TWO with  scale |v|_2 <= limit  and  scale max|v| < 2^ELEM_BITS: the integer column gets a norm in
+// (limit/2, limit] (`limit` = pgl_k_i8_norm_limit) unless its largest element would reach 2^50.  Powers of two on purpose: the scaling is
+// then exact, and so is the whole product for data with few significant bits -- spike counts, an identity basis -- whereas an arbitrary scale
+// rounds every occurrence of a repeated value the same way and those errors add up coherently (measured: 5x the random-rounding model
+// on basis-filtered spikes, up to sqrt(T) x on binary columns).  1 for an empty column, NaN for a non-finite one.
 __global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict__ amax, const double* __restrict__ ss, long n, double limit,
                                                         double* __restrict__ scale) {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
@@ -127,9 +132,13 @@ __global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict
     double s = 1.0;
     if (!(a < HUGE_VAL) || !(nrm < HUGE_VAL)) s = __builtin_nan("");
     else if (a > 0.0) {
-        const double cap = ldexp(1.0 - ldexp(1.0, -30), ELEM_BITS);
         const double nn = nrm > a ? nrm : a;
-        s = fmin(limit / nn, cap / a) * (1.0 - ldexp(1.0, -40));        // (the two quotients round to nearest: stay on the safe side)
+        int ea, en, el;
+        (void)frexp(a, &ea);                                             // a = m 2^ea, m in [0.5, 1): a 2^(ELEM_BITS - ea) < 2^ELEM_BITS
+        const double mn = frexp(nn, &en), ml = frexp(limit, &el);        // nn 2^e <= limit  <=>  mn 2^(en + e) <= ml 2^el
+        const int e_norm = el - en - (mn > ml ? 1 : 0);
+        const int e = min(ELEM_BITS - ea, e_norm);
+        s = ldexp(1.0, e);
     }
     scale[k] = s;
 }
@@ -692,21 +701,6 @@ int pgl_k_i8_min_planes(int T) {
     for (int k = 1; k <= NP; ++k)
         if (pgl_k_i8_nu(k, T) >= 50) return k;
     return NP + 1;
-}
-
-// How many moduli by default: the fewest (from 12) whose operand-rounding error, sqrt(2/12) / min(limit, 2^50) relative to |a_i||b_j|, stays
-// at or below 3/4 of the error of the kernel this path replaces -- the fp64 MFMA Gram, which accumulates T/4 steps in sequence and was
-// measured at rms 1.39e-17 sqrt(T) |a_i||b_j| on the bench's data (profiles/r02_f64_kernel_error.md: 4.4e-15 at T = 1e5, 2.2e-15 at 2e4).
-// 12 for T >= 87 000 (3.1e-15), 13 down to T = 410 (2.1e-16), 14 below.  tests/test_gpu_i8gram.py measures both sides on the device.
-int pgl_k_i8_auto_planes(int T) {
-    const double e64 = 1.39e-17 * std::sqrt((double)(T < 1 ? 1 : T));
-    for (int k = 12; k <= NP; ++k) {
-        const double lim = pgl_k_i8_norm_limit(k, T);
-        if (!(lim >= 256.0)) continue;
-        const double cap = std::ldexp(1.0, ELEM_BITS);
-        if (std::sqrt(2.0 / 12.0) / (lim < cap ? lim : cap) <= 0.75 * e64) return k;
-    }
-    return NP;
 }
 
 size_t pgl_k_i8_plane_bytes(int D, int T) {

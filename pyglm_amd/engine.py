@@ -127,9 +127,8 @@ class GibbsEngine(object):
         import os
         self.gram = gram or os.environ.get("PGL_GRAM", "auto")
         assert self.gram in ("auto", "fp64", "int8")
-        # number of residue planes (moduli) of the integer path: an int, or None / PGL_I8_PLANES unset = per data set the fewest whose
-        # rounding error stays below the fp64 kernel's own measured error (pgl_i8_auto_planes: 12 for T >= 87 000, else 13 / 14); 13 keeps
-        # it below the reference's CPU dgemm at any T; every further plane buys 4 more bits
+        # number of residue planes (moduli) of the integer path: an int, or None / PGL_I8_PLANES unset = pgl_i8_min_planes (13: integer
+        # column norms of 2^50, measured error several times below the fp64 kernel's own); every further plane buys 4 more bits
         planes = planes or os.environ.get("PGL_I8_PLANES")
         self.planes = int(planes) if planes else None
         assert self.planes is None or 1 <= self.planes <= _lib.load().pgl_i8_max_planes()
@@ -286,7 +285,7 @@ class GibbsEngine(object):
         if ds.int8:
             # residue planes of X (once per data set), scaled column by column from the columns' norms and maxima
             lib = _lib.load()
-            ds.planes = self.planes or lib.pgl_i8_auto_planes(T)
+            ds.planes = self.planes or lib.pgl_i8_min_planes(T)
             if lib.pgl_i8_norm_bits(ds.planes, T) < 8:
                 raise ValueError("%d residue planes cannot hold T = %d time bins" % (ds.planes, T))
             stat = self._z(2, self.D)
@@ -309,13 +308,9 @@ class GibbsEngine(object):
     I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
     I8_MIN_D, I8_MIN_T = 1024, 2048
 
-    @staticmethod
-    def _lib_auto(T):
-        return _lib.load().pgl_i8_auto_planes(int(T))
-
     def _i8_need(self, T, G, planes=None):
         lib = _lib.load()
-        planes = planes or self.planes or lib.pgl_i8_auto_planes(T)
+        planes = planes or self.planes or lib.pgl_i8_min_planes(T)
         return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D)) // lib.pgl_i8_max_planes() * planes
 
     def _use_int8(self, T):
@@ -337,22 +332,25 @@ class GibbsEngine(object):
         return fits
 
     def _i8_reserve(self, T, planes):
-        """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the largest data set seen so far"""
+        """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the largest data set seen so far
+        (planes and residues separately: a shorter data set may need more moduli, i.e. a larger residue buffer)"""
         lib = _lib.load()
         import os
-        if self._i8_scratch and self._i8_scratch[0] >= self._i8_need(T, self._i8_scratch[2], planes):
-            return
+        mp = lib.pgl_i8_max_planes()
+        pb1, r1 = lib.pgl_i8_plane_bytes(self.D, T) // mp * planes, lib.pgl_i8_residue_bytes(self.D) // mp * planes
+        if self._i8_scratch:
+            _, _, G, PB, R, _ = self._i8_scratch
+            if PB.numel() >= G * pb1 and R.numel() >= G * r1:
+                return
+            pb1, r1 = max(pb1, PB.numel() // G), max(r1, R.numel() // G)      # keep what earlier data sets need
         self._i8_scratch = None
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info(self.dev)
-        G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // self._i8_need(T, 1, planes))))
-        mp = lib.pgl_i8_max_planes()
-        self._i8_scratch = (self._i8_need(T, G, planes), T, G,
-                            torch.empty(G * lib.pgl_i8_plane_bytes(self.D, T) // mp * planes, dtype=torch.int8, device=self.dev),
-                            torch.empty(G * lib.pgl_i8_residue_bytes(self.D) // mp * planes, dtype=torch.int8, device=self.dev),
+        G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // (pb1 + r1))))
+        self._i8_scratch = (G * (pb1 + r1), T, G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
+                            torch.empty(G * r1, dtype=torch.int8, device=self.dev),
                             self._z(3, G, self.D))          # per group: column maxima, sums of squares, scales of omega_g X
 
-    @_on_device
     @_on_device
     def drop_int8(self, i):
         """put data set i on the fp64 Gram kernel and release its residue planes (the population model does this on every rank when ANY
@@ -363,6 +361,7 @@ class GibbsEngine(object):
             ds.PA = ds.sA = None
             torch.cuda.empty_cache()
 
+    @_on_device
     def set_noise(self, eta):
         """noise variances eta (nloc,) of the Gaussian observation model (regression.py:380-398)"""
         assert self.obs == 2

@@ -32,7 +32,6 @@ def test_library_exports_every_declared_symbol():
     # host-side constants of the integer Gram: bits of the column norms per number of moduli, fewest moduli at the fp64 level
     lib = _lib.load()
     assert [lib.pgl_i8_norm_bits(k, 100000) for k in (12, 13, 14, 15)] == [46, 50, 54, 58]
-    assert lib.pgl_i8_auto_planes(100000) == 12 and lib.pgl_i8_auto_planes(50000) == 13
     assert lib.pgl_i8_max_planes() == 15 and lib.pgl_i8_min_planes(100000) == 13 and 50.7 < __import__('math').log2(lib.pgl_i8_norm_limit(13, 100000)) < 50.8
 
 

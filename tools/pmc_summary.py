@@ -12,7 +12,7 @@ import sys
 
 
 def rows(d, counter, regex="i8_gram_kernel"):
-    f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     out = []
     for r in csv.DictReader(open(f)):
         if regex in r["Kernel_Name"] and r["Counter_Name"] == counter:
