@@ -121,9 +121,10 @@ class GibbsEngine(object):
         if self.R < 1:
             raise ValueError("B=%d too large for the proposal window" % self.B)
         self.datasets = []
-        # the likelihood Gram X'OX: "fp64" = the fp64-MFMA kernel; "int8" = exact integer arithmetic on the int8 MFMA (15 residue planes +
-        # CRT, pgl_i8_*; operands rounded to 50-bit fixed point per column -- error at the level of the fp64 product's own); "auto"
-        # (default) takes the integer path per data set where it is the faster one and its planes fit in memory (_use_int8)
+        # the likelihood Gram X'OX: "fp64" = the fp64-MFMA kernel; "int8" = exact integer arithmetic on the int8 MFMA (residue planes +
+        # CRT, pgl_i8_*; operands rounded to integers scaled from their column norms -- measured error several times below the fp64
+        # kernel's own); "auto" (default) takes the integer path per data set where it is the faster one and its
+        # planes fit in memory (_use_int8)
         import os
         self.gram = gram or os.environ.get("PGL_GRAM", "auto")
         assert self.gram in ("auto", "fp64", "int8")
@@ -149,7 +150,6 @@ class GibbsEngine(object):
         elif not design_only:
             self._alloc_batch()
             self._alloc_shard()
-        self.timings = {}
         self.keep_logodds = False       # True: sweep() leaves the flip log-odds in self.logodds (parity tests)
         self.logodds = None
         self.profile = False

@@ -90,3 +90,21 @@ def test_golden_model_sweep_through_the_c_abi_alone(golden, batch, timed):
     W2 = np.empty_like(W1)
     call("pgl_get_state", ctypes.byref(sw), a2.ctypes.data, W2.ctypes.data, None, None, status.ctypes.data, None)
     assert not status.any() and not np.array_equal(W2, W1) and np.all(W2[a2 == 0] == 0)
+
+
+def test_native_binder_runs_sweeps_without_python():
+    """examples/c_sweep/sweep_demo: C-style host code over include/pyglm_hip.h (hipMalloc'ed buffers, its own random inputs) runs a
+    few sweeps of a small model through pgl_sweep / pgl_get_state in a process of its own -- no Python, no torch"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_sweep", "sweep_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["hipcc", "-O2", "-I", os.path.join(root, "include"), exe + ".cpp", "-L", os.path.join(root, "pyglm_amd", "lib"),
+                               "-lpyglm_hip", "-Wl,-rpath,$ORIGIN/../../pyglm_amd/lib", "-o", exe])
+    out = subprocess.run([exe, "24", "3", "4000", "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("sweep")]
+    lls = [float(l.split("before")[1].split(",")[0]) for l in lines]
+    assert len(lls) == 6 and out.stdout.strip().endswith("ok")
+    assert max(lls[2:]) > lls[0]                       # the chain moves towards the data
