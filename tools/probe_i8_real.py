@@ -47,3 +47,4 @@ with torch.cuda.device(eng.dev):
         print("%-8s %9.3f ms%s" % (name, ms, extra), flush=True)
     zeros = float((PB[: ds.PA.numel()] == 0).float().mean())
     print("zero bytes in the first neuron's planes: %.3f" % zeros)
+    print("checksum of the group's Gram matrices: %.17g" % float(torch.tril(J[:D, :D]).double().sum()))
