@@ -52,6 +52,11 @@ def _sample_invwishart(S, nu, rng):
     return T.dot(T.T)
 
 
+def _take(W, mask):
+    """W[mask] for W (N, N, B), mask (N, N) bool -- the same rows in the same order, three times faster than boolean indexing"""
+    return np.ascontiguousarray(W).reshape(-1, W.shape[-1]).take(np.flatnonzero(mask), axis=0)
+
+
 class _NIW(object):
     """Gaussian with a normal-inverse-Wishart prior: resample(data) draws (mu, sigma) from the posterior."""
 
@@ -67,8 +72,14 @@ class _NIW(object):
         n = data.shape[0]
         mu_n, sigma_n, kappa_n, nu_n = self.mu_0, self.sigma_0, self.kappa_0, self.nu_0
         if n > 0:
-            xbar = data.mean(0)
-            centred = data - xbar
+            # same statistics as data.mean(0) and data - xbar, without NumPy's slow short-inner-loop paths on an (n, B) array (n ~ N^2):
+            # the mean as a matrix-vector product, the centring on rows of 64 observations at a time
+            xbar = np.ones(n).dot(data) / n
+            centred = np.empty_like(data)
+            n64 = n - n % 64
+            if n64:
+                np.subtract(data[:n64].reshape(n64 // 64, 64 * D), np.tile(xbar, 64), out=centred[:n64].reshape(n64 // 64, 64 * D))
+            centred[n64:] = data[n64:] - xbar
             dev = xbar - self.mu_0
             mu_n = (self.kappa_0 * self.mu_0 + n * xbar) / (self.kappa_0 + n)
             sigma_n = self.sigma_0 + centred.T.dot(centred) + self.kappa_0 * n / (self.kappa_0 + n) * np.outer(dev, dev)
@@ -150,10 +161,10 @@ class _IndependentGaussianMixin(_NetworkModel):
         A, W = data
         if self.is_diagonal_weight_special:
             eye = np.eye(self.N, dtype=bool)
-            self._gaussian.resample(W[A & ~eye])
-            self._self_gaussian.resample(W[A & eye])
+            self._gaussian.resample(_take(W, A & ~eye))
+            self._self_gaussian.resample(_take(W, A & eye))
         else:
-            self._gaussian.resample(W[A])
+            self._gaussian.resample(_take(W, A))
 
 
 class _FixedWeightsMixin(_NetworkModel):
