@@ -70,6 +70,7 @@ SIGNATURES = {
     "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
     "pgl_i8_scales": [c_p, c_p, c_l, c_i, c_i, c_p, c_p],
     "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_planes_t": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
@@ -90,7 +91,7 @@ SIGNATURES = {
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict
 
 // ------------------------------------------------------------------ fp64 -> residue planes
 struct PlaneArgs {
-    const double* X; long ldx;            // [T][ldx]
+    const double* X; long ldx;            // [T][ldx], or (transposed != 0) the transposed copy [D][ldx]
+    int transposed;
     const double* Om; long ldo;           // [T][ldo] weights of the group's neurons (null: unweighted, one "neuron")
     const double* scale;                  // [G][D] fixed-point scale of column d of neuron g (i8_scales_kernel)
     int8_t* P;                            // [G][np] planes of Dq * Kp bytes, blocked [Dq / 16][Kp / 64][16][64]
@@ -166,7 +167,11 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
     __shared__ double oms[PT_T];
     const int t0 = blockIdx.x * PT_T, d0 = blockIdx.y * PT_D;
     const int tid = threadIdx.x;
-    {
+    if (a.transposed) {                                    // rows of the transposed copy: one coalesced run of PT_T doubles per column
+        const int t = t0 + tid;
+#pragma unroll
+        for (int dl = 0; dl < PT_D; ++dl) tile[dl][tid] = (t < a.T && d0 + dl < a.D) ? a.X[(long)(d0 + dl) * a.ldx + t] : 0.0;
+    } else {                                               // 128-byte pieces of PT_T different rows
         const int dl = tid & (PT_D - 1), d = d0 + dl;
         for (int tl = tid / PT_D; tl < PT_T; tl += PT_T / PT_D) {
             const int t = t0 + tl;
@@ -180,9 +185,13 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
     const long nkt = a.Kp / 64;
     int8_t* const dst0 = a.P + (((long)blockIdx.y * nkt + kt) << 10) + l * 16;
     const long plane = (long)a.Dq * a.Kp;
+    const bool wrow = a.Om && t0 + tid < a.T;
+    const double* const omrow = a.Om ? a.Om + (long)(t0 + tid) * a.ldo : nullptr;
+    double om_next = wrow ? omrow[0] : 0.0;
     for (int gz = 0; gz < G; ++gz) {
         __syncthreads();                                   // the tile is staged / the previous neuron's weights are no longer read
-        if (a.Om) oms[tid] = t0 + tid < a.T ? a.Om[(long)(t0 + tid) * a.ldo + gz] : 0.0;
+        if (a.Om) oms[tid] = om_next;
+        if (gz + 1 < G) om_next = wrow ? omrow[gz + 1] : 0.0;         // the next neuron's weight is in flight while this one is converted
         __syncthreads();
         if (!live) continue;
         const double scale = d < a.D ? a.scale[(long)gz * a.D + d] : 0.0;
@@ -205,8 +214,12 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
                     const double pd = (double)MT.p[q], ip = 1.0 / pd;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
-                        const double qq = (v[k] * ip + MAGIC) - MAGIC;
-                        b[k] = (unsigned)__double2loint(fma(-pd, qq, vm[k]));
+                        // three instructions per residue.  (Left to the compiler, the second fma becomes a two-address v_fmac_f64 plus a
+                        // v_mov_b64 that copies v + M into its destination every time: a fourth.)
+                        const double qq = fma(v[k], ip, MAGIC) - MAGIC;
+                        double rr;
+                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rr) : "s"(-pd), "v"(qq), "v"(vm[k]));
+                        b[k] = (unsigned)__double2loint(rr);
                     }
                 }
                 v4i out;
@@ -216,7 +229,9 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
                     const unsigned hi = __builtin_amdgcn_perm(b[4 * j + 3], b[4 * j + 2], 0x0c0c0400u);
                     out[j] = (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
                 }
-                *reinterpret_cast<v4i*>(dst + (long)q * plane) = out;
+                // non-temporal: the planes are read next by another kernel, from HBM either way (53 GB per group); keeping them out of the
+                // write-back caches measured 5 % faster (12.95-13.2 vs 13.5-14.2 ms per group on one box)
+                __builtin_nontemporal_store(out, reinterpret_cast<v4i*>(dst + (long)q * plane));
             }
         }
     }
@@ -731,13 +746,14 @@ int pgl_k_i8_scales(const double* amax, const double* ss, long n, int T, int npl
 }
 
 // residue planes of X (Om == null, G = 1) or of omega_g X for the G weight columns Om[:, 0..G)
-int pgl_k_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, int8_t* P, int T, int D, int G, int nplanes,
-                    hipStream_t st) {
+int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om, long ldo, const double* scale, int8_t* P, int T, int D, int G,
+                    int nplanes, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
-    PlaneArgs a{X, ldx, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
-    // 256 time bins per workgroup (measured on one box, ms per group of 8: 128 bins 16.0, 256 15.0-15.2, 512 15.3)
-    hipLaunchKernelGGL(i8_planes_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
+    PlaneArgs a{X, ldx, transposed, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
+    // 512 time bins per workgroup: 8 KiB contiguous per plane and row block.  Measured on one box, ms per group of 8 at cfg3, with the
+    // non-temporal stores: 256 bins 13.6, 512 bins 12.5, 1024 bins 12.4 (with ordinary stores the three were within 2 %).
+    hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

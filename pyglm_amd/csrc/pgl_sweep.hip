@@ -220,7 +220,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
                     clk.toc(m);
                     m = clk.tic(ST_PLANES, (double)np * gz * d.T * D);
-                    RC(pgl_k_i8_planes(d.X, Dp, om, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), d.T, (int)D, gz, np, st));
+                    RC(pgl_k_i8_planes(d.Xt, d.Tp, 1, om, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), d.T, (int)D, gz, np, st));   // (coalesced rows of Xt)
                     clk.toc(m);
                     m = clk.tic(ST_I8, (double)gz * d.T * D * (D + 1));
                     RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), static_cast<const int8_t*>(s->i8_PB), static_cast<int8_t*>(s->i8_R), d.T, (int)D, gz, np, st));

@@ -293,7 +293,7 @@ class GibbsEngine(object):
             call("pgl_i8_colstats", ptr(ds.X), self.Dp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
             call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, ds.planes, ptr(ds.sA), st)
             ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
-            call("pgl_i8_planes", ptr(ds.X), self.Dp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
+            call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
             self._i8_reserve(T, ds.planes)
             torch.cuda.synchronize(self.dev)
         if self.obs == 2:
@@ -535,7 +535,7 @@ class GibbsEngine(object):
         npl = ds.planes
         call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
-        call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
+        call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
         call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)
         call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), Jp, ldj, ldj * ldj, ds.T, D, gz, npl, accumulate, st)
 

@@ -112,6 +112,34 @@ def test_residue_planes_match_numpy(k):
             assert not ((got - IB.T) % p).any() and got.min() >= -128 and got.max() <= 127
 
 
+@pytest.mark.parametrize("T,D,G", [(300, 37, 2), (1300, 70, 8), (777, 16, 1)])
+def test_planes_from_the_transposed_copy_are_the_same_bytes(T, D, G):
+    """pgl_i8_planes_t (what pgl_sweep uses: coalesced rows of Xt) against pgl_i8_planes, ragged time / column counts, leading dimensions
+    with padding"""
+    import torch
+    from pyglm_amd._lib import call, ptr, load
+    k = 13
+    X, Om = _data(T, D, G)
+    Xd, Od = torch.from_numpy(X).cuda(), torch.from_numpy(Om).cuda()
+    ldt = T + 5
+    Xt = torch.zeros(D, ldt, dtype=torch.float64, device="cuda:0")
+    Xt[:, :T] = Xd.t()
+    Xt[:, T:] = 9.0                                                                     # never read
+    lib = load()
+    Dq, Kp = lib.pgl_i8_padded_rows(D), max(256, -(-T // 64) * 64)
+    sA, sB = _scales(Xd, Od, T, D, G, k)
+    out = []
+    for name, Xa, ld in (("pgl_i8_planes", Xd, D), ("pgl_i8_planes_t", Xt, ldt)):
+        PA = torch.full((k * Dq * Kp,), 77, dtype=torch.int8, device="cuda:0")
+        PB = torch.full((G * k * Dq * Kp,), 77, dtype=torch.int8, device="cuda:0")
+        call(name, ptr(Xa), ld, None, 0, ptr(sA), ptr(PA), T, D, 1, k, None)
+        call(name, ptr(Xa), ld, ptr(Od), G, ptr(sB), ptr(PB), T, D, G, k, None)
+        torch.cuda.synchronize()
+        out.append((PA.cpu(), PB.cpu()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert out[0][1].float().abs().sum() > 0
+
+
 @pytest.mark.parametrize("T,D,G,k", [(5000, 300, 3, 13), (20000, 520, 2, 13), (20000, 260, 2, 14), (140000, 40, 1, 13), (300, 1700, 1, 13),
                                      (5000, 300, 8, 15), (5000, 300, 2, 12)])
 def test_integer_gram_matches_fp64_kernel_and_reference(T, D, G, k):
