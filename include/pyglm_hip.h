@@ -233,7 +233,7 @@ typedef struct {
     double* logodds;               /* optional out [nloc][N], see pgl_flip_t */
     /* scratch */
     double* Wt; double* bias; double* border; int* skip; double* c0_dense;   /* [Dp][ldn], [nloc], [2 ldn][Dp], [nloc], [nloc][N] (label only) */
-    double* Jbuf; double* Mtab; double* Ac;            /* [nb][ldj][ldj] each */
+    double* Jbuf; double* Mtab; double* Ac;            /* [nb][ldj][ldj] each; Ac may be the same buffer as Mtab (the tableau is dead when the weight draw starts) */
     double* hc; double* Tinv; double* G; double* Lws;  /* [2][nb][ldj], [nb][64][64], [nb][kmax][kmax], [nb][(kmax + 1)^2] */
     double* Ut; double* Wt_ws;     /* [nb][kmax][ldj] each */
     int* d_idx; double* d_sign; int* d_cnt; int* batch_k;   /* [nb][kmax], [nb][kmax], [nb], [nb] */

@@ -134,17 +134,23 @@ class GibbsEngine(object):
         self.planes = int(planes) if planes else None
         assert self.planes is None or 1 <= self.planes <= _lib.load().pgl_i8_max_planes()
         self._i8_scratch = None
-        per_neuron = 3 * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
+        # sweep tableau kept in proposal order (updates after a window touch only the rows not yet proposed); False keeps J's order and
+        # full-tableau updates -- same decisions, and the final tableau is then the complete sweep(A, S) (used by a full-size test)
+        self.visit_order = bool(visit_order)
+        # the compacted active block of the weight draw overlays the tableau, which is dead once a batch's flips are done (kept apart
+        # with visit_order=False, where tests read the final tableau): two (D+2)^2 buffers per neuron instead of three
+        self.share_tableau = self.visit_order
+        per_neuron = (2 if self.share_tableau else 3) * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
         if batch is None:
             free, _ = torch.cuda.mem_get_info(self.dev)
             budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * 0.45)
             batch = max(2, min(self.nloc, budget // per_neuron))
+            # equal batches: every batch pays the same latency-bound steps (one workgroup per neuron in the proposal and solve kernels,
+            # ~100 panel launches of the Cholesky), so 1024 neurons go as 4 x 256, not as 3 x 295 + 139 -- or, before the overlay, 5 x 204 + 4
+            batch = -(-self.nloc // -(-self.nloc // batch))
         self.nb = int(min(batch, self.nloc))
         self.design_only = design_only
         self.likelihood_only = bool(likelihood_only)
-        # sweep tableau kept in proposal order (updates after a window touch only the rows not yet proposed); False keeps J's order and
-        # full-tableau updates -- same decisions, and the final tableau is then the complete sweep(A, S) (used by a full-size test)
-        self.visit_order = bool(visit_order)
         if likelihood_only:
             self._alloc_shard()
         elif not design_only:
@@ -202,7 +208,7 @@ class GibbsEngine(object):
         self.Jslots = self._z(1, nb, ldj, ldj)
         self.Jbuf = self.Jslots[0]
         self.Mtab = self._z(nb, ldj, ldj)
-        self.Ac = self._z(nb, ldj, ldj)
+        self.Ac = self.Mtab if self.share_tableau else self._z(nb, ldj, ldj)
         self.hc = self._z(2, nb, ldj)
         self.Tinv = self._z(nb, 64, 64)
         self.G = self._z(nb, kmax, kmax)
