@@ -237,6 +237,84 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
     }
 }
 
+// The same conversion from the TRANSPOSED design matrix Xt [D][ldx], without the LDS tile: a lane's 16 consecutive time bins of its row are
+// 128 contiguous bytes of Xt, so it loads them straight into registers (a wave: 16 rows x 512 B) and keeps them for all G neurons.  The
+// weights of ALL G neurons for the workgroup's bins are staged in LDS once (64 contiguous bytes per bin in Om), so a tile has one barrier
+// instead of two per neuron, and the waves of a workgroup run independently of each other afterwards: the loads of one overlap the stores
+// of another.  (With the tile in LDS the pass over X cost 1.2-2 ms per call on top of ~1.2 ms per neuron of stores, unoverlapped.)
+template <int PT_T>
+__global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
+    __shared__ double oms[CS_G][PT_T + 2];
+    const int t0 = blockIdx.x * PT_T, d0 = blockIdx.y * PT_D;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, r = l >> 2, tb = 64 * w + 16 * (l & 3);
+    const long kt = t0 / 64 + w;
+    const bool live = kt * 64 < a.Kp;
+    const int d = d0 + r;
+    double x[16];
+    {
+        const int t = t0 + tb;
+        const double* src = a.X + (long)d * a.ldx + t;
+        if (live && d < a.D && t + 16 <= a.T) {                      // (rows of Xt are 16-byte aligned: ldx even, t a multiple of 16)
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                const double2 v2 = *reinterpret_cast<const double2*>(src + k);
+                x[k] = v2.x; x[k + 1] = v2.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = (live && d < a.D && t + k < a.T) ? src[k] : 0.0;
+        }
+    }
+    if (a.Om) {
+        const int t = t0 + tid;
+        const double* src = a.Om + (long)t * a.ldo;
+        for (int g = 0; g < G; ++g) oms[g][tid] = t < a.T ? src[g] : 0.0;
+        __syncthreads();
+    }
+    if (!live) return;
+    const long nkt = a.Kp / 64;
+    int8_t* const dst0 = a.P + (((long)blockIdx.y * nkt + kt) << 10) + l * 16;
+    const long plane = (long)a.Dq * a.Kp;
+    for (int gz = 0; gz < G; ++gz) {
+        const double scale = d < a.D ? a.scale[(long)gz * a.D + d] : 0.0;
+        double v[16], vm[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = rint((a.Om ? x[k] * oms[gz][tb + k] : x[k]) * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
+            vm[k] = v[k] + MAGIC;
+        }
+        int8_t* dst = dst0 + (long)gz * a.np * plane;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (q < a.np) {
+                unsigned b[16];
+                if (q == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) b[k] = (unsigned)__double2loint(vm[k]);
+                } else {
+                    const double pd = (double)MT.p[q], ip = 1.0 / pd;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const double qq = fma(v[k], ip, MAGIC) - MAGIC;
+                        double rr;
+                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rr) : "s"(-pd), "v"(qq), "v"(vm[k]));
+                        b[k] = (unsigned)__double2loint(rr);
+                    }
+                }
+                v4i out;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned lo = __builtin_amdgcn_perm(b[4 * j + 1], b[4 * j], 0x0c0c0400u);
+                    const unsigned hi = __builtin_amdgcn_perm(b[4 * j + 3], b[4 * j + 2], 0x0c0c0400u);
+                    out[j] = (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                }
+                __builtin_nontemporal_store(out, reinterpret_cast<v4i*>(dst + (long)q * plane));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ int8 Gram of the planes, reduced mod p
 constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
 constexpr int STAGE_BYTES = (TM + TN) * BKB;
@@ -753,7 +831,14 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
     PlaneArgs a{X, ldx, transposed, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
     // 512 time bins per workgroup: 8 KiB contiguous per plane and row block.  Measured on one box, ms per group of 8 at cfg3, with the
     // non-temporal stores: 256 bins 13.6, 512 bins 12.5, 1024 bins 12.4 (with ordinary stores the three were within 2 %).
-    hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
+    const bool aligned = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
+    static const bool lds_tile = getenv("PGL_PLANES_LDS") != nullptr;                  // A/B switch: the LDS-tile kernel on Xt as well
+    if (transposed && aligned && !lds_tile)
+        // measured on one box per variant pair, ms per group of 8 at cfg3 (the LDS-tile kernel on Xt: 11.9): 768 threads 11.3-11.4, 512 10.7-10.8
+        // (137 VGPRs, one workgroup per CU; forced to 128 VGPRs with 16 spills: 11.3-11.4), 256 9.85-10.1, 128 10.3-10.6
+        hipLaunchKernelGGL(i8_planes_t_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
+    else
+        hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
