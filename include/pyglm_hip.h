@@ -118,8 +118,6 @@ double pgl_i8_norm_limit(int nplanes, int T);    /* norm of the integer columns 
 size_t pgl_i8_plane_bytes(int D, int T);
 size_t pgl_i8_residue_bytes(int D);
 int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* hip_stream);
-/* the same statistics, bit for bit (same summation order), read from the transposed copy Xt [D][ldt]: coalesced, what pgl_sweep uses */
-int pgl_i8_colstats_t(const double* Xt, long ldt, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* hip_stream);
 int pgl_i8_scales(const double* amax, const double* sumsq, long ncols, int T, int nplanes, double* scale, void* hip_stream);
 int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
                   void* hip_stream);

@@ -68,7 +68,6 @@ SIGNATURES = {
     "pgl_i8_norm_bits": [c_i, c_i],
     "pgl_i8_norm_limit": [c_i, c_i],
     "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
-    "pgl_i8_colstats_t": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
     "pgl_i8_scales": [c_p, c_p, c_l, c_i, c_i, c_p, c_p],
     "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_planes_t": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -153,11 +153,7 @@ double pgl_i8_norm_limit(int nplanes, int T) { return pgl_k_i8_norm_limit(nplane
 #define PGL_CHECK_PLANES(np, T) PGL_CHECK_ARG((np) >= 1 && (np) <= pgl_k_i8_max_planes() && pgl_k_i8_nu((np), (T)) >= 8)
 int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* st) {
     PGL_CHECK_ARG(X && amax && sumsq && T > 0 && D > 0 && G >= 1 && G <= 8 && ldx >= D && (Om == nullptr ? G == 1 : ldo >= G));
-    return pgl_k_i8_colstats(X, ldx, 0, Om, ldo, T, D, G, amax, sumsq, ST(st));
-}
-int pgl_i8_colstats_t(const double* Xt, long ldt, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* st) {
-    PGL_CHECK_ARG(Xt && amax && sumsq && T > 0 && D > 0 && G >= 1 && G <= 8 && ldt >= T && (Om == nullptr ? G == 1 : ldo >= G));
-    return pgl_k_i8_colstats(Xt, ldt, 1, Om, ldo, T, D, G, amax, sumsq, ST(st));
+    return pgl_k_i8_colstats(X, ldx, Om, ldo, T, D, G, amax, sumsq, ST(st));
 }
 int pgl_i8_scales(const double* amax, const double* sumsq, long ncols, int T, int nplanes, double* scale, void* st) {
     PGL_CHECK_ARG(amax && sumsq && scale && ncols > 0 && T > 0);

@@ -101,7 +101,7 @@ int pgl_k_i8_padded_rows(int);
 int pgl_k_i8_min_planes(int);
 int pgl_k_i8_nu(int, int);
 double pgl_k_i8_norm_limit(int, int);
-int pgl_k_i8_colstats(const double*, long, int transposed, const double*, long, int, int, int, double*, double*, hipStream_t);
+int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
 int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
 int pgl_k_i8_planes(const double*, long, int transposed, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);
 int pgl_k_i8_gram(const int8_t*, const int8_t*, int8_t*, int, int, int, int, hipStream_t);

@@ -65,19 +65,14 @@ constexpr int ELEM_BITS = 50;          // |scaled element| < 2^50: the residue t
 // the scales, and with them every bit of J, do not depend on launch timing.  A NaN / inf in a column makes its sum of squares
 // non-finite; i8_scales_kernel turns that into a NaN scale (the Gram of that column is then NaN, as on the fp64 kernel).
 constexpr int CS_COLS = 16, CS_LANES = 64, CS_G = 8, CS_ROWS = 4;     // a pass stages CS_LANES * CS_ROWS = 256 time bins of omega
-// TRANSPOSED: X is the transposed copy [D][ldx]; a WAVE then owns a column (64 consecutive time bins per load: 512 contiguous bytes instead of
-// 16 columns' 128 bytes of 64 different rows).  Time lane l still sums the bins t = l (mod 64) in increasing order and the 64 lanes are
-// folded in the same order, so both variants return the same bits.
-template <int G, bool WEIGHTED, bool TRANSPOSED = false>
+template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const double* __restrict__ X, long ldx, const double* __restrict__ Om,
                                                                         long ldo, int T, int D, double* __restrict__ amax,
                                                                         double* __restrict__ ss) {
     constexpr int CH = CS_LANES * CS_ROWS;
     __shared__ double red[2][CS_LANES][CS_COLS + 1];
-    // the weights of a pass: [bin][g] where the lanes of a wave share their bins (broadcast reads), [g][bin] where every lane has its own
-    __shared__ double oms[WEIGHTED ? (TRANSPOSED ? G : CH) : 1][WEIGHTED ? (TRANSPOSED ? CH : G) : 1];
-    const int tid = threadIdx.x, cl = TRANSPOSED ? tid / CS_LANES : tid % CS_COLS, tl = TRANSPOSED ? tid % CS_LANES : tid / CS_COLS;
-    const int c = blockIdx.x * CS_COLS + cl;
+    __shared__ double oms[WEIGHTED ? CH : 1][WEIGHTED ? G : 1];
+    const int tid = threadIdx.x, cl = tid % CS_COLS, tl = tid / CS_COLS, c = blockIdx.x * CS_COLS + cl;
     const bool live = c < D;
     double m[G], q[G];
 #pragma unroll
@@ -87,8 +82,7 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
             __syncthreads();
             for (int e = tid; e < CH * G; e += CS_COLS * CS_LANES) {
                 const int t = t0 + e / G;
-                const double w = t < T ? Om[(long)t * ldo + e % G] : 0.0;
-                if (TRANSPOSED) oms[e % G][e / G] = w; else oms[e / G][e % G] = w;
+                oms[e / G][e % G] = t < T ? Om[(long)t * ldo + e % G] : 0.0;
             }
             __syncthreads();
         }
@@ -96,14 +90,13 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
 #pragma unroll
         for (int r = 0; r < CS_ROWS; ++r) {              // CS_ROWS independent loads in flight per thread
             const int t = t0 + tl + r * CS_LANES;
-            x[r] = (live && t < T) ? (TRANSPOSED ? X[(long)c * ldx + t] : X[(long)t * ldx + c]) : 0.0;
+            x[r] = (live && t < T) ? X[(long)t * ldx + c] : 0.0;
         }
 #pragma unroll
         for (int r = 0; r < CS_ROWS; ++r)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const double w = WEIGHTED ? (TRANSPOSED ? oms[g][tl + r * CS_LANES] : oms[tl + r * CS_LANES][g]) : 1.0;
-                const double v = WEIGHTED ? x[r] * w : x[r];                              // the same product the planes kernel rounds
+                const double v = WEIGHTED ? x[r] * oms[tl + r * CS_LANES][g] : x[r];       // the same product the planes kernel rounds
                 m[g] = fmax(m[g], fabs(v));               // (a NaN is dropped here and caught through the sum of squares)
                 q[g] = fma(v, v, q[g]);
             }
@@ -812,18 +805,12 @@ size_t pgl_k_i8_residue_bytes(int D) {
     return (size_t)NP * Dq * Dq;
 }
 
-int pgl_k_i8_colstats(const double* X, long ldx, int transposed, const double* Om, long ldo, int T, int D, int G, double* amax, double* ss,
-                      hipStream_t st) {
+int pgl_k_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* ss, hipStream_t st) {
     if (G > CS_G || G < 1) { pgl_set_error("i8 colstats: %d weight columns per call (max %d)", G, CS_G); return PGL_ERR_ARG; }
     const dim3 grid((D + CS_COLS - 1) / CS_COLS), block(CS_COLS * CS_LANES);
-#define PGL_CS(g_) case g_: \
-        if (transposed) hipLaunchKernelGGL((i8_colstats_kernel<g_, true, true>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss); \
-        else hipLaunchKernelGGL((i8_colstats_kernel<g_, true, false>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss); \
-        break;
-    if (!Om) {
-        if (transposed) hipLaunchKernelGGL((i8_colstats_kernel<1, false, true>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss);
-        else hipLaunchKernelGGL((i8_colstats_kernel<1, false, false>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss);
-    } else switch (G) { PGL_CS(1) PGL_CS(2) PGL_CS(3) PGL_CS(4) PGL_CS(5) PGL_CS(6) PGL_CS(7) PGL_CS(8) default: break; }
+#define PGL_CS(g_) case g_: hipLaunchKernelGGL((i8_colstats_kernel<g_, true>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss); break;
+    if (!Om) hipLaunchKernelGGL((i8_colstats_kernel<1, false>), grid, block, 0, st, X, ldx, Om, ldo, T, D, amax, ss);
+    else switch (G) { PGL_CS(1) PGL_CS(2) PGL_CS(3) PGL_CS(4) PGL_CS(5) PGL_CS(6) PGL_CS(7) PGL_CS(8) default: break; }
 #undef PGL_CS
     PGL_CHECK_LAUNCH();
     return PGL_OK;

@@ -216,7 +216,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     const int gz = G < nbb - g0 ? G : nbb - g0;
                     const double* om = d.OK + s0 + g0;
                     auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
-                    RC(pgl_k_i8_colstats(d.Xt, d.Tp, 1, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
+                    RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
                     RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
                     clk.toc(m);
                     m = clk.tic(ST_PLANES, (double)np * gz * d.T * D);

@@ -296,7 +296,7 @@ class GibbsEngine(object):
                 raise ValueError("%d residue planes cannot hold T = %d time bins" % (ds.planes, T))
             stat = self._z(2, self.D)
             ds.sA = self._z(self.D)
-            call("pgl_i8_colstats_t", ptr(ds.Xt), ds.Tp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
+            call("pgl_i8_colstats", ptr(ds.X), self.Dp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
             call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, ds.planes, ptr(ds.sA), st)
             ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
             call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
@@ -539,7 +539,7 @@ class GibbsEngine(object):
         _, _, G, PB, R, stat = self._i8_scratch
         assert gz <= G
         npl = ds.planes
-        call("pgl_i8_colstats_t", ptr(ds.Xt), ds.Tp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
+        call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
         call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
         call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)

@@ -28,8 +28,7 @@ with torch.cuda.device(eng.dev):
     om = ctypes.c_void_p(ds.OK.data_ptr())
     ldo = 2 * eng.ldn
     J = eng.Jslots[0]
-    stages = [("stats X", lambda: call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, T, D, nl, ptr(stat[0]), ptr(stat[1]), None)),
-              ("stats", lambda: (call("pgl_i8_colstats_t", ptr(ds.Xt), ds.Tp, om, ldo, T, D, nl, ptr(stat[0]), ptr(stat[1]), None),
+    stages = [("stats", lambda: (call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, T, D, nl, ptr(stat[0]), ptr(stat[1]), None),
                                  call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), nl * D, T, k, ptr(stat[2]), None))),
               ("planes X", lambda: call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
               ("planes", lambda: call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
