@@ -53,6 +53,16 @@ __global__ __launch_bounds__(256) void gather_table_kernel(const double* __restr
     if (e < n) out[e] = table[label[e]];
 }
 
+// out[e] (+)= partial[0][e] + partial[1][e] + ... in slice order (the split contraction of the border sums)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ partial, long n, int S, double* __restrict__ out, int accumulate,
+                                                         int ld, int ncols) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n || e % ld >= ncols) return;                 // (the slices' padding columns were never written)
+    double acc = accumulate ? out[e] : 0.0;
+    for (int k = 0; k < S; ++k) acc += partial[(long)k * n + e];
+    out[e] = acc;
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ p, long n, double v) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e < n) p[e] = v;
@@ -174,7 +184,30 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
         auto m = clk.tic(ST_BORDER, 4.0 * d.T * (D + 1) * nloc);
-        RC(pgl_contract_tn(d.OK, 2 * ldn, 2 * ldn, d.X, Dp, Dp, s->border, Dp, 2 * ldn, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
+        // The output is small (2 nloc x (D+1)) and the contraction long (T): with few neurons it is a handful of 128 x 256 tiles -- 6
+        // workgroups at N = 128, 42 on a 128-neuron shard of cfg3 -- each walking all of T.  Then T is cut into S slices, one batch of the
+        // GEMM each, whose partial sums go to the (still unused) J buffer and are added up in slice order by one small kernel.
+        const long tiles = (long)((2 * ldn + 127) / 128) * ((D + 1 + 255) / 256);
+        const long part = (long)2 * ldn * Dp;
+        long S = 2L * pgl_device_cus(pgl_device()) / tiles;
+        if (S > 64) S = 64;
+        if (S > d.Tp / 256) S = d.Tp / 256;
+        if (S > (long)nb * strideJ / part) S = (long)nb * strideJ / part;
+        if (S >= 2) {
+            const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
+            PglGemmArgs a{};
+            a.A = d.OK; a.lda = 2 * ldn; a.strideA = (long)chunk * a.lda; a.a_cols = 2 * ldn;
+            a.B = d.X; a.ldb = Dp; a.strideB = (long)chunk * Dp; a.b_cols = Dp;
+            a.C = s->Jbuf; a.ldc = Dp; a.strideC = part;
+            a.M = 2 * ldn; a.N = (int)D + 1; a.K = chunk; a.nbatch = (int)S; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
+            RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
+            if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
+                a.A = d.OK + (long)S * chunk * a.lda; a.B = d.X + (long)S * chunk * Dp; a.K = rem; a.nbatch = 1; a.beta = 1.0;
+                RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
+            }
+            hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, s->Jbuf, part, (int)S, s->border, i > 0, Dp, (int)D + 1);
+            PGL_CHECK_LAUNCH();
+        } else RC(pgl_contract_tn(d.OK, 2 * ldn, 2 * ldn, d.X, Dp, Dp, s->border, Dp, 2 * ldn, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
         clk.toc(m);
     }
     // ---- deterministic rows, status, optional log-odds record, block-prior constants
