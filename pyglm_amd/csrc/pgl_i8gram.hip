@@ -833,7 +833,7 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
     // non-temporal stores: 256 bins 13.6, 512 bins 12.5, 1024 bins 12.4 (with ordinary stores the three were within 2 %).
     const bool aligned = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
     static const bool lds_tile = getenv("PGL_PLANES_LDS") != nullptr;                  // A/B switch: the LDS-tile kernel on Xt as well
-    if (transposed && aligned && !lds_tile)
+    if (transposed && aligned && !lds_tile && G <= CS_G)       // (the register kernel stages at most CS_G weight columns; more: the tile kernel)
         // measured on one box per variant pair, ms per group of 8 at cfg3 (the LDS-tile kernel on Xt: 11.9): 768 threads 11.3-11.4, 512 10.7-10.8
         // (137 VGPRs, one workgroup per CU; forced to 128 VGPRs with 16 spills: 11.3-11.4), 256 9.85-10.1, 128 10.3-10.6
         hipLaunchKernelGGL(i8_planes_t_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
