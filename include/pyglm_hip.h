@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 5
+#define PGL_ABI_VERSION 6
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -81,6 +81,15 @@ int pgl_weighted_gram(const double* X, long ldx, int x_cols, const double* W, lo
  * pyglm/regression.py:253-260 with A = [Omega | Kappa] and X carrying the ones column). */
 int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long ldb, int b_cols, double* C, long ldc, int M, int N, int K,
                     double alpha, double beta, void* hip_stream);
+/* The same contraction for a batch of independent operands, C[b] = beta C[b] + alpha A[b]' B[b], b < nbatch (operands strideX doubles apart):
+ * the rank-k products of the collapsed flips (M -= W'U on every neuron's sweep tableau; pyglm/regression.py:282-320, where the reference
+ * refactors the active block per proposal) and of the blocked Cholesky of the weight draw (pyglm/regression.py:323-340).
+ * tri: 0 all tiles, 1 the tiles of the lower triangle (M == N), 2 of the upper.  batch_k: optional per-batch K (multiples of 16, 0 = skip).
+ * kernel: 0 generic tiles, 1 the update pipeline (256 x 128 tiles, DMA-staged, persistent) where it is the faster one, 2 always the
+ * pipeline -- every choice gives the same bits (tests/test_gpu_update.py). */
+int pgl_contract_tn_batched(const double* A, long lda, long strideA, int a_cols, const double* B, long ldb, long strideB, int b_cols, double* C,
+                            long ldc, long strideC, int M, int N, int K, int nbatch, const int* batch_k, double alpha, double beta, int tri,
+                            int kernel, void* hip_stream);
 /* J_post = J_lkhd + J_prior, h_post = h_lkhd + h_prior in the (D+2)-square layout [J, bias row D, potential row D+1].
  * Replaces _prior_sufficient_statistics + the additions at pyglm/regression.py:210-223, 253-260, 270-271.
  * border: 2*nloc_b rows (omega sums then kappa sums) x ldb; Jb [nb], hb [nb]; the block-diagonal prior either dense, Jw [nb][N][B][B] and

@@ -74,6 +74,7 @@ SIGNATURES = {
     "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
+    "pgl_contract_tn_batched": [c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_d, c_d, c_i, c_i, c_p],
     "pgl_assemble_posterior": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "pgl_flip_kmax": [],
     "pgl_flip_window_blocks": [c_i],
@@ -91,7 +92,7 @@ SIGNATURES = {
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -135,6 +135,18 @@ int pgl_contract_tn(const double* A, long lda, int a_cols, const double* B, long
     return pgl_launch_gemm(PGL_GEMM_PLAIN, a, ST(st));
 }
 
+int pgl_contract_tn_batched(const double* A, long lda, long strideA, int a_cols, const double* B, long ldb, long strideB, int b_cols, double* C,
+                            long ldc, long strideC, int M, int N, int K, int nbatch, const int* batch_k, double alpha, double beta, int tri,
+                            int kernel, void* st) {
+    PGL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % 16 == 0 && ldc >= N && nbatch > 0 && tri >= 0 && tri <= 2 && kernel >= 0 && kernel <= 2);
+    PGL_CHECK_ARG(tri == 0 || M == N);
+    PglGemmArgs a{};
+    a.A = A; a.lda = lda; a.strideA = strideA; a.B = B; a.ldb = ldb; a.strideB = strideB; a.C = C; a.ldc = ldc; a.strideC = strideC;
+    a.M = M; a.N = N; a.K = K; a.a_cols = a_cols & ~1; a.b_cols = b_cols & ~1;
+    a.nbatch = nbatch; a.alpha = alpha; a.beta = beta; a.tri = tri; a.batch_k = batch_k; a.pipe = kernel;
+    return pgl_launch_gemm(tri ? PGL_GEMM_TRI1 : PGL_GEMM_PLAIN, a, ST(st));
+}
+
 int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* border_omega, const double* border_kappa, long ldb, const double* Jw,
                            const double* hw, const int* label, const double* Jb, const double* hb, int nb, int N, int B, void* st) {
     PGL_CHECK_ARG(J && border_omega && border_kappa && Jw && hw && Jb && hb && nb > 0 && N > 0 && B > 0);

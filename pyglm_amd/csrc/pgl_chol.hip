@@ -261,7 +261,7 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
         // strip: mfix rows only -- and never rows past a neuron's own remainder (they would land in the padding or, beyond ldc, in the next
         // neuron's block)
         if (mfix > 0) { t.M = mfix; t.tri = 0; t.dim_mode = 3; return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st); }
-        t.M = rem; t.tri = 2; t.dim_mode = 0;
+        t.M = rem; t.tri = 2; t.dim_mode = 0; t.pipe = 1;
         return pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     };
     auto panel_solve = [&](int q0) -> int {

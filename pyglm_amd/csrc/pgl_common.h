@@ -63,9 +63,13 @@ struct PglGemmArgs {
     int* sched;                                // persistent launch: 8 per-XCD work counters, zeroed before the launch
     const int* batch_dim; int dim_off;         // optional per-batch size d = max(0, batch_dim[b] - dim_off)
     int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed;  3: M = min(g.M, d), N = d
+    int pipe;                                  // 1: a rank-k product of the flips / the Cholesky: may take the update pipeline (pgl_update.hip) where that is faster; 2: must
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
+// the update pipeline (pgl_update.hip): 256 x 128 tiles, DMA-staged, persistent; pgl_launch_gemm routes products marked `pipe` to it
+bool pgl_update_supported(const PglGemmArgs& a);
+int pgl_launch_update(const PglGemmArgs& a, hipStream_t st);
 // 8 zeroed per-XCD work counters for one persistent launch on stream st (a ring of slots owned by the library; pgl_gemm.hip)
 int* pgl_sched_slot(hipStream_t st);
 

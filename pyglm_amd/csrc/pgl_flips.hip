@@ -667,6 +667,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
     w.C = s.Wt + r0; w.ldc = s.ldu; w.strideC = (long)KMAX * s.ldu;
     w.M = KMAX; w.N = ncol; w.K = KMAX; w.a_cols = KMAX; w.b_cols = ncol; w.nbatch = s.nb; w.nz_total = 0;
     w.alpha = 1.0; w.beta = 0.0; w.tri = 0; w.batch_k = s.batch_k; w.batch_dim = s.batch_k; w.dim_off = 0; w.dim_mode = 2; w.W = nullptr; w.ldw = 0;   // only the first K rows of W are non-zero / used
+    w.pipe = 1;
     int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st);
     if (rc) return rc;
     PglGemmArgs t{};
@@ -675,6 +676,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
     t.C = s.M + (long)r0 * s.ldj + r0; t.ldc = s.ldj; t.strideC = s.strideM;
     t.M = Md - r0; t.N = Md - r0; t.K = KMAX; t.a_cols = ncol; t.b_cols = ncol; t.nbatch = s.nb; t.nz_total = 0;
     t.alpha = -1.0; t.beta = 1.0; t.tri = 1; t.batch_k = s.batch_k; t.batch_dim = nullptr; t.dim_off = 0; t.W = nullptr; t.ldw = 0;
+    t.pipe = 1;
     rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     if (rc) return rc;
     if (r0 == 0) {                   // (trailing form: the pivot rows / columns are dead, nothing to rewrite)

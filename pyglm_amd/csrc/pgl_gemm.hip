@@ -788,6 +788,15 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
     PGL_CHECK_ARG(a.K % BK == 0 && a.M > 0 && a.N > 0 && a.nbatch > 0);
     PGL_CHECK_ARG(a.a_cols % 2 == 0 && a.b_cols % 2 == 0 && a.lda % 2 == 0 && a.ldb % 2 == 0);
     PGL_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0);
+    if (a.pipe && kind != PGL_GEMM_GRAM2) {
+        // products marked `pipe` (the rank-k updates of the flips and the Cholesky, W = G U) may take the update pipeline of pgl_update.hip.
+        // Measured at cfg3 (tools/ubench_update.hip, same bits on both kernels): the write-only form (beta = 0: W = G U) is 8-23 % faster
+        // there; the read-modify-write forms are not (one persistent workgroup per CU cannot hide a tile's 512 KiB of C traffic behind
+        // another workgroup's MFMAs: 62.0 vs 62.2 TFLOP/s at rank 512, 0.77x at rank 64) and stay on the generic kernel.
+        // PGL_UPDATE_PIPE=0: never; =all: every supported product (A/B switch).
+        static const int mode = [] { const char* e = getenv("PGL_UPDATE_PIPE"); return !e ? 1 : e[0] == '0' ? 0 : e[0] == 'a' ? 2 : 1; }();
+        if (mode && (mode == 2 || a.pipe == 2 || a.beta == 0.0) && pgl_update_supported(a)) return pgl_launch_update(a, st);
+    }
     switch (kind) {
         case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); {
             // production: persistent, DMA-staged 3-stage pipeline; PGL_GRAM_STAGES=2 selects the generic 2-stage kernel (debugging aid)
