@@ -30,10 +30,15 @@ CONFIGS = {   # BASELINE.json configs
     "cfg3": dict(N=1024, B=5, T=100000, L=100),
     "cfg4": dict(N=512, B=5, T=100000, L=100, obs="negbin"),      # NegativeBinomialGLM (dense prior): PG shape b = y + xi
     "cfg3g": dict(N=1024, B=5, T=100000, L=100, obs="gaussian"),  # not in BASELINE.json: SparseGaussianGLM at the cfg3 shape
+    # configs[4]: dense-network prior (rho = 1: one 32 769-dim Cholesky per neuron), 8 x MI355X.  One neuron's residue planes are 86 GB, so the
+    # integer Gram runs in time slices; a rank's shard is 512 neurons at ~1.3 s each, so the bench times `--neurons k` of them
+    "cfg5": dict(N=4096, B=8, T=200000, L=100, dense=True, neurons=8),
 }
 PEAK_HBM_GBS = 8000.0
 PEAK_I8_MFMA_TOPS = 5000.0    # dense i8 MFMA, 2x the bf16 figure of MI355X_MICROARCH.md (4.92 POP/s measured at 2.39 GHz on constant operands)
 PEAK_F64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 64 cyc (tools/ubench2_f64.hip, measured)
+UBENCH_I8_MFMA_TOPS = 3944.0  # what MI355X_MICROARCH.md's i8 MFMA micro-benchmark sustains (the nominal peak is not reachable under the power cap)
+TIMED_STAGES = ("gram", "gram.int8", "gram.planes", "gram_scale")     # stages that keep their HIP events inside the timed region
 TOP_STAGES = ("activation", "pg_loglik", "border", "gram", "gram.stats", "gram.planes", "gram.int8", "gram.crt", "gram_scale", "flips", "weights")
 
 
@@ -98,6 +103,91 @@ def cpu_baseline(model, cfg, neurons=2, proposals=32, budget_s=150.0):
                           time.perf_counter() - t_wall))
 
 
+class PowerWatch(object):
+    """samples the GPU's graphics clock and socket power (amdsmi, 5 Hz, ~0.5 ms per sample, on a host thread) while a region runs, so that
+    the bench line itself says at which clock and power the roofline number was measured"""
+
+    def __init__(self, period=0.2):
+        self.period, self.samples, self._stop, self._thread, self.err = period, [], False, None, None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            want = os.environ.get("PGL_BENCH_DEVICE") or os.environ.get("LOCAL_RANK") or "0"
+            self._h = hs[int(want)] if int(want) < len(hs) else hs[0]
+            self._smi = amdsmi
+        except Exception as e:          # no amdsmi / no permission: the line then simply carries no clock record
+            self._smi, self.err = None, repr(e)
+
+    def _loop(self):
+        smi = self._smi
+        while not self._stop:
+            try:
+                p = smi.amdsmi_get_power_info(self._h)
+                c = smi.amdsmi_get_clock_info(self._h, smi.AmdSmiClkType.GFX)
+                w = p.get("current_socket_power", p.get("socket_power"))
+                self.samples.append((time.perf_counter(), float(w), float(c["clk"])))
+            except Exception as e:
+                self.err = repr(e)
+                return
+            time.sleep(self.period)
+
+    def start(self):
+        if self._smi is None:
+            return self
+        import threading
+        self.samples, self._stop = [], False
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        if not self.samples:
+            return {"available": False, "error": self.err}
+        w = np.array([x[1] for x in self.samples])
+        c = np.array([x[2] for x in self.samples])
+        return {"available": True, "samples": len(w), "period_s": self.period, "sclk_mhz_mean": float(c.mean()), "sclk_mhz_min": float(c.min()),
+                "sclk_mhz_max": float(c.max()), "power_w_mean": float(w.mean()), "power_w_max": float(w.max()),
+                "source": "amdsmi (amdsmi_get_clock_info GFX, amdsmi_get_power_info current_socket_power) sampled over the timed region"}
+
+
+def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8), sweeps=2):
+    """One rank's share of a G-GPU run of the same model, on this GPU: rank 0 of G owns neurons [0, N/G) (models.py:169-171 sharded by
+    postsynaptic neuron, shard_bounds); its sweep is pgl_sweep over those neurons (engine.sweep(nrun=N/G): same kernels, same batches as
+    a real rank would use at this batch size), then the all_gather of (a, W, b) rows and the network prior, which every rank repeats on
+    the host.  The first two are timed here; the all_gather cannot be (one GPU) and is given as its payload.  NOT measured scaling."""
+    import torch
+    inputs = model._sweep_inputs()
+    state = model.get_state()
+    t0 = time.perf_counter()
+    model.resample_network()
+    t_net = time.perf_counter() - t0
+    model.set_state(state)
+    rows = []
+    for G in groups:
+        k = N // G
+        eng.profile = True
+        eng.collect_timings()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(sweeps):
+            eng.sweep(*inputs, model.seed, model.sweeps_done, nrun=k)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / sweeps
+        st = eng.collect_timings()
+        eng.profile = False
+        rows.append({"gpus": G, "neurons_per_rank": k, "batches": -(-k // eng.nb), "rank_sweep_ms": dt * 1e3,
+                     "rank_sweep_plus_network_ms": (dt + t_net) * 1e3, "projected_sweeps_per_s": 1.0 / (dt + t_net),
+                     "stages_ms": {n: round(v["ms"] / sweeps, 1) for n, v in st.items() if n in TOP_STAGES}})
+    return {"note": "one-rank proxy, not measured scaling: the sweep of the first N/G neurons from the bench chain's current state on THIS GPU "
+                    "(%d sweeps each), plus the replicated host-side network prior; the per-sweep all_gather of the (a, W, b) rows is not included" % sweeps,
+            "host_network_prior_ms": t_net * 1e3, "allgather_payload_bytes": int(N * N + 8 * N * N * B + 8 * N),
+            "per_gpu_count": rows}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without torchrun: N child processes of this same script, one per GPU, rendezvous on 127.0.0.1 at a free
     port.  Children inherit stdout/stderr (only rank 0 prints the JSON line).  Any rank failing ends the others; exit code = first failure."""
@@ -110,6 +200,8 @@ def self_launch(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if os.environ.get("PGL_BENCH_DEVICE"):
+            env.setdefault("PGL_DEVICE_SHARE", str(n))     # ranks sharing one GPU (test hook): each engine budgets 1/n of its memory
         # the host side of a rank (NumPy / BLAS for the priors and the random inputs) must not claim every core of the node n times over
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -147,7 +239,12 @@ def main():
     ap.add_argument("--planes", type=int, default=None, help="residue planes (moduli) of the integer Gram (default: the engine's, 13)")
     ap.add_argument("--no-fp64-compare", action="store_true",
                     help="skip the extra sweeps (untimed for `value`) that fill int8_vs_fp64 and fp64_gram_path")
-    ap.add_argument("--fp64-steps", type=int, default=3, help="sweeps timed with the Gram on the fp64-MFMA kernel for fp64_gram_path")
+    ap.add_argument("--fp64-steps", type=int, default=1, help="sweeps timed with the Gram on the fp64-MFMA kernel for fp64_gram_path")
+    ap.add_argument("--neurons", type=int, default=None,
+                    help="time only the first k neurons of this rank's shard (a config whose shard is hours of work per sweep: cfg5); the line is "
+                         "then seconds per neuron, labelled extrapolated")
+    ap.add_argument("--no-scaling-proxy", action="store_true",
+                    help="skip scaling_proxy (one rank's shard of a 2 / 4 / 8-GPU run, timed on this GPU; N = 1 only)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("N", "T", "B"):
@@ -214,37 +311,56 @@ def main():
         Y = rg.standard_normal((T, N)) + 2.0 * Y                                                      # real-valued activity
         model = SparseGaussianGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, a_0=2.0, b_0=2.0), seed=0, engine_kwargs=ekw)
     else:
-        model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=0, engine_kwargs=ekw)
+        mkw = {}
+        k_neurons = args.neurons or cfg.get("neurons")
+        if k_neurons:
+            # k neurons of this rank's shard (rank r of `world` owns N / world neurons starting at lo)
+            lo = rank * (N // max(world, 1))
+            mkw["shard"] = (lo, min(N, lo + k_neurons))
+        if cfg.get("dense"):
+            from pyglm_amd.networks import NIWDenseNetwork
+            mkw["network"] = NIWDenseNetwork(N, B)          # rho = 1: regression.py:153-155 -> deterministic rows, one dense draw per neuron
+        model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=10.0, mu_b=-2.0), seed=0, engine_kwargs=ekw, **mkw)
     model.add_data(Y)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     eng = model.engine
 
-    def timed(steps):
+    watch = PowerWatch() if rank == 0 else None
+
+    def timed(steps, profile=TIMED_STAGES, watched=False):
         """`steps` sweeps bracketed by barrier + synchronize on both sides -> (max-over-ranks seconds, this rank's seconds, stage table,
-        seconds this rank spent inside collectives)"""
-        eng.profile = True
+        seconds this rank spent inside collectives).  profile: the stages whose launches are bracketed by HIP events on the launch
+        stream (True: all of them -- a few thousand event pairs per sweep, kept out of the region `value` is measured on)"""
+        eng.profile = profile
         eng.collect_timings()
         c0 = model.comm_seconds
         barrier()
+        if watched and watch:
+            watch.start()
         t0 = time.perf_counter()
         for _ in range(steps):
             model.resample_model()
         barrier()
         mine = time.perf_counter() - t0
+        pw = watch.stop() if (watched and watch) else None
         st = eng.collect_timings()
         eng.profile = False
-        return allmax(mine), mine, st, model.comm_seconds - c0
+        return allmax(mine), mine, st, model.comm_seconds - c0, pw
 
     for _ in range(args.warmup):
         model.resample_model()
-    dt, dt_mine, stages, comm_s = timed(args.steps)
+    dt, dt_mine, stages, comm_s, power = timed(args.steps, watched=True)
+    # the stage table: one further sweep with every stage timed (not part of `value`)
+    dt_prof, _, stages_all, _, _ = timed(1, profile=True)
+    for k_, v_ in stages.items():          # the dominant kernels keep the numbers of the timed region
+        stages_all[k_] = dict(v_, ms=v_["ms"] / args.steps, calls=v_["calls"] / args.steps, work=v_["work"] / args.steps)
 
     # per-rank breakdown: wall time, time inside collectives, GPU time of the top-level stages, and what is left (host-only share)
-    gpu_ms = sum(v["ms"] for k, v in stages.items() if k in TOP_STAGES)
+    gpu_ms = sum(v["ms"] for k, v in stages_all.items() if k in TOP_STAGES)        # per sweep (stages_all is normalised to one sweep)
     mine = {"rank": rank, "neurons": model.n1 - model.n0, "ms_per_step": dt_mine / args.steps * 1e3,
-            "collectives_ms_per_step": comm_s / args.steps * 1e3, "gpu_stage_ms_per_step": gpu_ms / args.steps,
-            "host_only_ms_per_step": max(0.0, dt_mine * 1e3 - gpu_ms) / args.steps}
+            "collectives_ms_per_step": comm_s / args.steps * 1e3, "gpu_stage_ms_per_step": gpu_ms,
+            "host_only_ms_per_step": max(0.0, dt_mine / args.steps * 1e3 - gpu_ms)}
     per_rank = [mine]
     if use_dist:
         per_rank = [None] * world
@@ -256,10 +372,16 @@ def main():
     barrier()
     t_ll = time.perf_counter() - t_ll          # log_likelihood() on its own: activation + fused reduction (+ scalar all-reduce)
 
+    # ---- what ONE rank of a 2 / 4 / 8-GPU run does, timed here (the driver's multi-GPU run is the measurement; this is the stand-in a
+    # one-GPU box can give): the sweep of the first N/G neurons of this model from its current state (not advanced), twice each
+    scaling = None
+    if world == 1 and not args.no_scaling_proxy and not model._shard_override and cfg.get("obs") is None and N % 8 == 0 and N >= 64:
+        scaling = scaling_proxy(model, eng, N, B, T)
+
     # ---- the two Gram paths from the same state (consistency), then the fp64 path timed on its own
     cmp64 = consistency = None
     took_i8 = bool(allmax(float(any(ds.int8 for ds in eng.datasets))))      # every rank runs the extra sweeps, or none
-    if took_i8 and not args.no_fp64_compare:
+    if took_i8 and not args.no_fp64_compare and not model._shard_override:
         state = model.get_state()
         model.resample_model()
         ll_i8 = model.log_likelihood()
@@ -267,7 +389,7 @@ def main():
         model.set_state(state)
         for ds in eng.datasets:
             ds.int8 = False
-        d1, _, st64, _ = timed(1)
+        d1, _, st64, _, _ = timed(1)
         ll_f64 = model.log_likelihood()
         A_f64, W_f64 = model.adjacency, model.weights
         consistency = {"note": "one sweep from the same chain state with the Gram on the integer matrix cores and on the fp64 kernel",
@@ -278,7 +400,7 @@ def main():
         more = max(0, args.fp64_steps - 1)
         d2, st2 = 0.0, {}
         if more:
-            d2, _, st2, _ = timed(more)
+            d2, _, st2, _, _ = timed(more)
         nst = 1 + more
         dt64 = d1 + d2
         g64 = {k: st64.get("gram", {}).get(k, 0.0) + st2.get("gram", {}).get(k, 0.0) for k in ("ms", "calls", "work")}
@@ -316,7 +438,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
                          "traffic": None, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
-            "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
+            "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages_all.items()},
+            "stages_note": "ms per sweep on rank 0; %s from HIP events inside the timed region (averaged over its %d sweeps), every other stage from "
+                           "one further, fully instrumented sweep (%.1f ms) that is not part of `value`" % (", ".join(k for k in TIMED_STAGES if k in stages),
+                                                                                                        args.steps, dt_prof * 1e3),
             "per_rank": per_rank,
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll, "log_likelihood_ms": round(t_ll * 1e3, 2),
         }
@@ -339,6 +464,7 @@ def main():
                                "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"], "planes": npl,
                                "algorithmic_ops_per_launch": npl * gi["work"] / gi["calls"],
                                "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,
+                               "frac_vs_ubench": ach / UBENCH_I8_MFMA_TOPS, "ubench_tops": UBENCH_I8_MFMA_TOPS,
                                "power_limited_mfma_only_tops": 4000.0}
             gp = stage("gram.planes")
             if gp["ms"] > 0:
@@ -352,7 +478,17 @@ def main():
                 out["int8_vs_fp64"] = consistency
             if cmp64:
                 out["fp64_gram_path"] = cmp64
-        pl = stage("pg_loglik")
+        out["roofline"]["clock_power"] = power            # graphics clock and socket power sampled while the timed region ran
+        if scaling is not None:
+            out["scaling_proxy"] = scaling
+        if model._shard_override:
+            k_ = model.n1 - model.n0
+            out["shard_sample"] = {"neurons_timed": k_, "first_neuron": model.n0, "s_per_neuron": dt / args.steps / k_,
+                                   "note": "`value` and ms_per_step are for these %d neurons only (one rank's shard of this config is %d neurons at "
+                                           "%d GPUs: %.0f s per sweep per rank by extrapolation -- neurons are independent and of equal cost, "
+                                           "models.py:169-171); the network prior (host, replicated on every rank) is in the timed region once per sweep"
+                                           % (k_, N // 8, 8, dt / args.steps / k_ * (N // 8))}
+        pl = stages_all.get("pg_loglik", dict(ms=0.0, work=0.0))
         if pl["ms"] > 0:
             out["stage_E_note"] = ("pg_loglik_kernel: %.1f M PG draws/s; bound by the sampler's transcendental VALU work (rejection loops), not by "
                                    "HBM (40 B per draw = %.2f TB/s)" % (pl["work"] / (pl["ms"] * 1e-3) * 1e-6, 40.0 * pl["work"] / (pl["ms"] * 1e-3) * 1e-12))
@@ -363,7 +499,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "scaled_gram_kernel (J[n] = X'X / eta_n, lower triangle)", "achieved": ach,
                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS if ach else None, "traffic": None,
                                "launches": gs["calls"], "avg_launch_ms": gs["ms"] / gs["calls"] if gs["calls"] else None}
-        if not args.no_cpu_baseline and world == 1 and cfg.get("obs") is None:
+        if not args.no_cpu_baseline and world == 1 and cfg.get("obs") is None and not model._shard_override:
             out["cpu_baseline"] = cpu_baseline(model, cfg)
         else:
             out["cpu_baseline"] = None

@@ -135,6 +135,13 @@ int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const d
 int pgl_i8_planes_t(const double* Xt, long ldt, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
                     void* hip_stream);
 int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, int nplanes, void* hip_stream);
+/* One time slice [t0, t0 + T_slice) of the same product, for data sets whose planes do not fit in memory at once (BASELINE configs[4]:
+ * 86 GB of planes per neuron): planes_wx holds the slice only (pgl_i8_planes_t on the slice's rows); planes_x either the whole data set
+ * (T_x = its bins; the slice is read at t0, a multiple of 64) or a slice of its own (T_x = 0).  accumulate: add to the residues of the
+ * earlier slices.  T_total = bins of the whole product (it fixes the moduli the scales were chosen for).  The integer Gram is a sum over
+ * time, so slices add up exactly. */
+int pgl_i8_gram_slice(const void* planes_x, int T_x, int t0, const void* planes_wx, void* residues, int T_slice, int T_total, int D, int G,
+                      int nplanes, int accumulate, void* hip_stream);
 int pgl_i8_crt(const void* residues, const double* scale_x, const double* scale_wx, double* J, long ldj, long strideJ, int T, int D, int G,
                int nplanes, int accumulate, void* hip_stream);
 
@@ -211,7 +218,7 @@ typedef struct {
     int int8;                      /* 1: likelihood Gram on the integer matrix cores (sA, PA valid); 0: fp64 MFMA kernel */
     int planes;                    /* moduli of this data set's planes (0: pgl_sweep_t.planes) */
     const double* sA;              /* [D] column scales of X (pgl_i8_scales) */
-    const void* PA;                /* residue planes of X (pgl_i8_planes), `planes` of them */
+    const void* PA;                /* residue planes of X (pgl_i8_planes), `planes` of them; NULL: converted per time slice into pgl_sweep_t.i8_PAs */
     const double* omega_override;  /* optional [T][nloc]: replaces the PG draws (test hook: the reference fixtures inject omega) */
 } pgl_dataset_t;
 
@@ -221,6 +228,8 @@ typedef struct {                   /* host; zero-initialise.  Per stage (pgl_sta
     double work[PGL_NSTAGES];
     int calls[PGL_NSTAGES];
     void* pending;                 /* events recorded by pgl_sweep and not yet folded in by pgl_stage_times_collect */
+    unsigned int mask;             /* 0: time every stage; else only the stages whose bit (1 << index) is set (a timed benchmark region
+                                    * keeps the dominant kernel's events and drops the other few thousand per sweep) */
 } pgl_stage_times_t;
 
 typedef struct {
@@ -249,6 +258,12 @@ typedef struct {
     int* act; int* na;             /* [nb][D + 1], [nb] */
     void* i8_PB; void* i8_R; double* i8_stat;          /* integer Gram: i8_group * pgl_i8_plane_bytes, i8_group * pgl_i8_residue_bytes (each
                                     * * planes / 15 suffices), [3][i8_group][D] */
+    int i8_slice;                  /* time bins per slice of the integer Gram (a multiple of 64; 0 = the whole data set at once): i8_PB then
+                                    * holds i8_group slices of pgl_i8_plane_bytes(D, i8_slice) */
+    void* i8_PAs;                  /* planes of one slice of X, pgl_i8_plane_bytes(D, i8_slice): used for data sets with int8 = 1 and PA = NULL
+                                    * (their X planes are converted per slice instead of kept) */
+    int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
+                                    * this GPU (bench.py scaling_proxy); the state of the others is left alone */
     /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */
     int all_deterministic;         /* 1: the caller knows every row has rho in {0, 1} (regression.py:153-155): the flip stage is not launched */
     int init_rows_bound;           /* upper bound of 1 + B * (active blocks of any local neuron) BEFORE the sweep */

@@ -31,7 +31,7 @@ NSTAGES = 16
 
 
 class StageTimes(ctypes.Structure):  # pgl_stage_times_t
-    _fields_ = [("ms", c_d * NSTAGES), ("work", c_d * NSTAGES), ("calls", c_i * NSTAGES), ("pending", c_p)]
+    _fields_ = [("ms", c_d * NSTAGES), ("work", c_d * NSTAGES), ("calls", c_i * NSTAGES), ("pending", c_p), ("mask", c_u32)]
 
 
 class Sweep(ctypes.Structure):       # pgl_sweep_t
@@ -42,7 +42,7 @@ class Sweep(ctypes.Structure):       # pgl_sweep_t
                 ("Wt", c_p), ("bias", c_p), ("border", c_p), ("skip", c_p), ("c0_dense", c_p),
                 ("Jbuf", c_p), ("Mtab", c_p), ("Ac", c_p), ("hc", c_p), ("Tinv", c_p), ("G", c_p), ("Lws", c_p), ("Ut", c_p), ("Wt_ws", c_p),
                 ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("act", c_p), ("na", c_p),
-                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p),
+                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p), ("i8_slice", c_i), ("i8_PAs", c_p), ("nrun", c_i),
                 ("all_deterministic", c_i), ("init_rows_bound", c_i), ("active_rows_bound", c_i), ("times", ctypes.POINTER(StageTimes))]
 
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_planes_t": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_gram_slice": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p],
     "pgl_contract_tn": [c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_d, c_d, c_p],
     "pgl_contract_tn_batched": [c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_d, c_d, c_i, c_i, c_p],

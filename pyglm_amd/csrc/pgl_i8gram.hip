@@ -332,6 +332,8 @@ struct GramArgs {
     int idle_wave;                        // 320-tile kernel: the wave above the diagonal of a diagonal tile idles
     int kt0;                              // 320-tile kernel only: first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
+    long KpA; int ka0;                    // the X planes may be longer than this slice of the omega X planes: their bytes per row, first K tile
+    int accum;                            // 320-tile kernel: add to the residues already in R (a later time slice of the same product)
 };
 
 __device__ __forceinline__ int isqrt_tri_i(int t) {
@@ -370,7 +372,7 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const long plane = (long)g.Dq * g.Kp;
-    const int8_t* A = g.PA + (long)q * plane;
+    const int8_t* A = g.PA + (long)q * g.Dq * g.KpA + (long)g.ka0 * 1024;
     const int8_t* B = g.PB + ((long)gz * g.np + q) * plane;
     const int nkt = (int)(g.Kp / BKB);
 
@@ -385,7 +387,7 @@ __device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, co
     for (int i = 0; i < 4; ++i) {
         const int rq = wv + 8 * i;
         const int lc = (lane & 3) ^ chunk_swz((lane >> 4) & 3);
-        const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.Kp : B + (long)(n0 + 16 * rq - TM) * g.Kp;
+        const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.KpA : B + (long)(n0 + 16 * rq - TM) * g.Kp;
         gp[i] = reinterpret_cast<const char*>(base) + (lane >> 2) * 64 + lc * 16;
         loff[i] = rq * 1024;
     }
@@ -531,7 +533,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const long plane = (long)g.Dq * g.Kp;
-    const int8_t* A = g.PA + (long)q * plane;
+    const int8_t* A = g.PA + (long)q * g.Dq * g.KpA + (long)g.ka0 * 1024;
     const int8_t* B = g.PB + ((long)gz * g.np + q) * plane;
     const int nkt = (int)(g.Kp / BKB);
     // DMA: per K tile 640 rows x 64 B = 40 requests of 1 KiB; wave w issues requests w, w+4, ..., w+36 (row blocks 0..19 = A, 20..39 = B).
@@ -560,7 +562,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int rq = wv + 4 * i;
-            const int8_t* base = rq < 20 ? A + (long)(m0 + 16 * rq) * g.Kp : B + (long)(n0 + 16 * (rq - 20)) * g.Kp;
+            const int8_t* base = rq < 20 ? A + (long)(m0 + 16 * rq) * g.KpA : B + (long)(n0 + 16 * (rq - 20)) * g.Kp;
             sb[i] = reinterpret_cast<const char*>(base) + (long)kc * 1024;
         }
         long gadv = nk >= 2 ? 1024 : 0;   // 0 once the pass's last tile has been requested: the cursors stop (redundant re-requests into a dead stage)
@@ -662,7 +664,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
                         *dst8 = (int8_t)(v & 0xff);          // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
                     }
         };
-        if (kc == 0) store(std::false_type{});
+        if (kc == 0 && !g.accum) store(std::false_type{});
         else store(std::true_type{});
     }
 }
@@ -726,37 +728,65 @@ struct CrtArgs {
     int D, Dq, G, accumulate, np;
 };
 
+// 1 / x for a scale: a power of two (exponent arithmetic: no division), 1 for an empty column, NaN for a non-finite one
+__device__ __forceinline__ double recip_scale(double x) {
+    const long long b = __double_as_longlong(x);
+    const bool pow2 = (b & 0x000FFFFFFFFFFFFFll) == 0 && b > 0x0010000000000000ll && b < 0x7FD0000000000000ll;
+    return pow2 ? __longlong_as_double(0x7FE0000000000000ll - b) : 1.0 / x;      // (anything else takes the division: NaN stays NaN)
+}
+
+// A thread reconstructs FOUR consecutive entries of a row: the residues of a plane are one 4-byte load instead of four single bytes
+// (the byte-per-thread version issued 13 one-byte loads per entry and ran at 1.7 TB/s of its 21 bytes per entry), the result is two
+// 16-byte stores.
 __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, gz = blockIdx.z;
-    if (j > i || i >= a.D) return;
-    const int8_t* R = a.R + ((long)gz * a.np) * a.Dq * a.Dq + (long)i * a.Dq + j;
-    int v[NP];
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4, i = blockIdx.y, gz = blockIdx.z;
+    if (j0 > i || i >= a.D) return;
+    const int8_t* R = a.R + ((long)gz * a.np) * a.Dq * a.Dq + (long)i * a.Dq + j0;
+    int w[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) v[q] = q < a.np ? (int)R[(long)q * a.Dq * a.Dq] : 0;
-    // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...;  digit q =
-    // (r_q - sum_{k<q} v_k (p_0..p_{k-1} mod p_q)) (p_0..p_{q-1})^-1 mod p_q: the sum is accumulated unreduced (14 terms of at most
-    // 128 * 128), so a digit costs q multiply-adds and ONE reduction instead of q reductions
+    for (int q = 0; q < NP; ++q) w[q] = q < a.np ? *reinterpret_cast<const int*>(R + (long)q * a.Dq * a.Dq) : 0;
+    const double ra = recip_scale(a.sA[i]);
+    double out[4];
 #pragma unroll
-    for (int q = 1; q < NP; ++q) {
-        if (q < a.np) {
-            const int p = MT.p[q];
-            int u = v[q];
+    for (int e = 0; e < 4; ++e) {
+        int v[NP];
 #pragma unroll
-            for (int k = 0; k < q; ++k) u -= v[k] * MT.w[k][q];                          // |u| < 2^18
-            int t = u * MT.pinv[q] % p;                                                   // < 2^26 in magnitude
-            if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
-            v[q] = t;
+        for (int q = 0; q < NP; ++q) v[q] = (int)(int8_t)((unsigned)w[q] >> (8 * e));
+        // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...;  digit q =
+        // (r_q - sum_{k<q} v_k (p_0..p_{k-1} mod p_q)) (p_0..p_{q-1})^-1 mod p_q: the sum is accumulated unreduced (14 terms of at most
+        // 128 * 128), so a digit costs q multiply-adds and ONE reduction instead of q reductions
+#pragma unroll
+        for (int q = 1; q < NP; ++q) {
+            if (q < a.np) {
+                const int p = MT.p[q];
+                int u = v[q];
+#pragma unroll
+                for (int k = 0; k < q; ++k) u -= v[k] * MT.w[k][q];                          // |u| < 2^18
+                int t = u * MT.pinv[q] % p;                                                   // < 2^26 in magnitude
+                if (t > p / 2) t -= p; else if (t < -(p / 2)) t += p;
+                v[q] = t;
+            }
         }
-    }
-    double s = 0.0;
+        double s = 0.0;
 #pragma unroll
-    for (int q = NP - 1; q >= 0; --q)
-        if (q < a.np) s = s * (double)MT.p[q] + (double)v[q];
-    // non-finite data (a diverged chain): the scale of that column is NaN and so is every entry it takes part in, as the fp64 product
-    // would give -- never a finite number made of garbage residues.  Two divisions: the product of two scales may overflow.
-    const double val = (s / a.sA[i]) / a.sB[(long)gz * a.D + j];
-    double* dst = a.J + (long)gz * a.strideJ + (long)i * a.ldj + j;
-    *dst = a.accumulate ? *dst + val : val;
+        for (int q = NP - 1; q >= 0; --q)
+            if (q < a.np) s = s * (double)MT.p[q] + (double)v[q];
+        // non-finite data (a diverged chain): the scale of that column is NaN and so is every entry it takes part in, as the fp64 product
+        // would give -- never a finite number made of garbage residues.  Two factors, applied one after the other: the product of two
+        // scales may overflow.  The scales are powers of two, so multiplying by their reciprocals IS the division.
+        const int j = j0 + e;
+        const double rb = j < a.D ? recip_scale(a.sB[(long)gz * a.D + j]) : 0.0;
+        out[e] = (s * ra) * rb;
+    }
+    double* dst = a.J + (long)gz * a.strideJ + (long)i * a.ldj + j0;
+    if (j0 + 3 <= i && !a.accumulate && (reinterpret_cast<uintptr_t>(dst) % 16 == 0)) {
+        *reinterpret_cast<d2_t*>(dst) = d2_t{out[0], out[1]};
+        *reinterpret_cast<d2_t*>(dst + 2) = d2_t{out[2], out[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j0 + e <= i) dst[e] = a.accumulate ? dst[e] + out[e] : out[e];
+    }
 }
 
 }  // namespace
@@ -796,6 +826,7 @@ int pgl_k_i8_min_planes(int T) {
     return NP + 1;
 }
 
+long pgl_k_i8_kp(int T) { return pgl_i8_kp(T); }
 size_t pgl_k_i8_plane_bytes(int D, int T) {
     const long Dq = pgl_k_i8_padded_rows(D), Kp = pgl_i8_kp(T);
     return (size_t)NP * Dq * Kp;
@@ -843,10 +874,15 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
     return PGL_OK;
 }
 
-int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, int G, int nplanes, hipStream_t st) {
+// One time slice of the product: PB (and R's geometry) belong to the slice of T bins; the X planes start at K tile ka0 of rows that are KpA
+// bytes long (KpA = 0: they are a slice of their own, same geometry as PB).  accumulate: add to the residues of the earlier slices.
+int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t* R, int T, int D, int G, int nplanes, int accumulate, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     const bool big = pgl_i8_tile() == BT;
+    if (KpA <= 0) { KpA = Kp; ka0 = 0; }
+    if (KpA % BKB != 0 || (long)(ka0 + Kp / BKB) * BKB > KpA) { pgl_set_error("i8 gram: slice of %ld bytes at tile %d outside the X planes (%ld)", Kp, ka0, KpA); return PGL_ERR_ARG; }
+    if (accumulate && !big) { pgl_set_error("i8 gram: time slices need the 320-tile kernel (PGL_I8_TILE=256 is set)"); return PGL_ERR_ARG; }
     // LDS stages of the 320-tile kernel: 3 (requests one tile ahead).  A fourth stage (two tiles ahead, all 160 KiB) measured 6.7 % SLOWER on
     // real planes (107.2 vs 100.5 ms per launch of 8 neurons at cfg3): the 32 workgroups of an XCD then hold 3 x 40 KiB in flight each, which
     // is the whole 4 MiB L2, and the strips they share fall out of it.  PGL_I8_STAGES=4 keeps the variant measurable.
@@ -866,7 +902,7 @@ int pgl_k_i8_gram(const int8_t* PA, const int8_t* PB, int8_t* R, int T, int D, i
         static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();   // A/B switch: "chunk"
         // super-blocks of 6 x 6 tiles (measured on one box, ms per launch: 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
         static const bool idle_off = [] { const char* e = getenv("PGL_I8_IDLE"); return e && e[0] == '0'; }();                  // A/B switch
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, idle_off ? 0 : 1, kt0, pgl_sched_slot(st)};
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, idle_off ? 0 : 1, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         if (big && big_stages == 4) hipLaunchKernelGGL((i8_gram_kernel<true, 4>), dim3(grid), dim3(256), 4 * BSTAGE, st, g);
         else if (big) hipLaunchKernelGGL((i8_gram_kernel<true, 3>), dim3(grid), dim3(256), 3 * BSTAGE, st, g);
@@ -881,7 +917,7 @@ int pgl_k_i8_crt(const int8_t* R, const double* sA, const double* sB, double* J,
     const int Dq = pgl_k_i8_padded_rows(D);
     if (G <= 0) return PGL_OK;
     CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes};
-    hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 255) / 256, D, G), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 1023) / 1024, D, G), dim3(256), 0, st, c);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

@@ -79,7 +79,7 @@ struct Clock {     // HIP events around a stage, on the launch stream; inert whe
     struct Mark { int stage; hipEvent_t e0; double work; bool on; };
     Mark tic(int stage, double work = 0.0) {
         Mark m{stage, nullptr, work, false};
-        if (!t) return m;
+        if (!t || (t->mask && !((t->mask >> stage) & 1u))) return m;
         if (hipEventCreate(&m.e0) != hipSuccess) return m;
         (void)hipEventRecord(m.e0, st);
         m.on = true;
@@ -140,7 +140,10 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     PGL_CHECK_ARG(s->Wt && s->bias && s->border && s->skip && s->Jbuf && s->Mtab && s->Ac && s->hc && s->Tinv && s->G && s->Lws && s->Ut && s->Wt_ws);
     PGL_CHECK_ARG(s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->act && s->na && (s->label == nullptr || s->c0_dense != nullptr));
     PGL_CHECK_ARG(s->obs != 2 || (s->inv_eta && s->G0));
-    const int N = s->N, B = s->B, nloc = s->nloc, nb = s->nb < nloc ? s->nb : nloc;
+    PGL_CHECK_ARG(s->nrun >= 0 && s->nrun <= s->nloc && s->i8_slice >= 0 && s->i8_slice % 64 == 0);
+    const int N = s->N, B = s->B, nloc = s->nloc;
+    const int nrun = s->nrun > 0 ? s->nrun : nloc;        // neurons actually swept (a prefix of the shard; the array layouts stay the shard's)
+    const int nb = s->nb < nrun ? s->nb : nrun;
     const long D = (long)N * B;
     const int Dp = r_up(D + 1, 16), ldn = r_up(nloc, 2), ldj = r_up(D + 2, 16);
     const long strideJ = (long)ldj * ldj;
@@ -151,7 +154,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
         PGL_CHECK_ARG(d.T > 0 && d.Tp >= d.T && d.Tp % 16 == 0 && d.X && d.Xt && d.Y && d.Psi && d.OK && d.llpart);
-        PGL_CHECK_ARG(!d.int8 || (d.sA && d.PA && (d.planes > 0 || s->planes > 0)));
+        PGL_CHECK_ARG(!d.int8 || (d.sA && (d.PA || (s->i8_PAs && s->i8_slice > 0)) && (d.planes > 0 || s->planes > 0)));
         any_i8 = any_i8 || d.int8;
     }
     PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= 8 && s->obs != 2));
@@ -167,12 +170,12 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     }
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
-        auto m = clk.tic(ST_ACT, 2.0 * d.T * D * nloc);
-        RC(pgl_activation(d.Xt, d.Tp, s->Wt, ldn, d.Psi, ldn, d.T, Dp, nloc, st));
+        auto m = clk.tic(ST_ACT, 2.0 * d.T * D * nrun);
+        RC(pgl_activation(d.Xt, d.Tp, s->Wt, ldn, d.Psi, ldn, d.T, Dp, nrun, st));
         clk.toc(m);
-        m = clk.tic(ST_PG, (double)d.T * nloc);
-        if (s->obs == 2) RC(pgl_k_gaussian_stats(d.Psi, ldn, s->bias, d.Y, ldn, s->inv_eta, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nloc, st));
-        else RC(pgl_k_pg_loglik(d.Psi, ldn, s->bias, d.Y, ldn, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nloc, s->obs, s->xi, seed, sweep,
+        m = clk.tic(ST_PG, (double)d.T * nrun);
+        if (s->obs == 2) RC(pgl_k_gaussian_stats(d.Psi, ldn, s->bias, d.Y, ldn, s->inv_eta, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nrun, st));
+        else RC(pgl_k_pg_loglik(d.Psi, ldn, s->bias, d.Y, ldn, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nrun, s->obs, s->xi, seed, sweep,
                                 (uint64_t)s->n0, d.elem0, st));
         clk.toc(m);
         if (d.omega_override) {       // test hook: the reference fixtures inject omega
@@ -183,31 +186,40 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     // ---- border sums [Omega|Kappa]' [X, 1]  (regression.py:253-260)
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
-        auto m = clk.tic(ST_BORDER, 4.0 * d.T * (D + 1) * nloc);
+        auto m = clk.tic(ST_BORDER, 4.0 * d.T * (D + 1) * nrun);
         // The output is small (2 nloc x (D+1)) and the contraction long (T): with few neurons it is a handful of 128 x 256 tiles -- 6
         // workgroups at N = 128, 42 on a 128-neuron shard of cfg3 -- each walking all of T.  Then T is cut into S slices, one batch of the
         // GEMM each, whose partial sums go to the (still unused) J buffer and are added up in slice order by one small kernel.
-        const long tiles = (long)((2 * ldn + 127) / 128) * ((D + 1 + 255) / 256);
+        // (a prefix run -- nrun < nloc -- contracts the Omega and the Kappa columns of its neurons as two pieces)
+        const int npieces = nrun < nloc ? 2 : 1;
+        const int Mp = nrun < nloc ? r_up(nrun, 2) : 2 * ldn;
+        const long tiles = (long)((Mp + 127) / 128) * ((D + 1 + 255) / 256) * npieces;
         const long part = (long)2 * ldn * Dp;
         long S = 2L * pgl_device_cus(pgl_device()) / tiles;
         if (S > 64) S = 64;
         if (S > d.Tp / 256) S = d.Tp / 256;
         if (S > (long)nb * strideJ / part) S = (long)nb * strideJ / part;
-        if (S >= 2) {
-            const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
-            PglGemmArgs a{};
-            a.A = d.OK; a.lda = 2 * ldn; a.strideA = (long)chunk * a.lda; a.a_cols = 2 * ldn;
-            a.B = d.X; a.ldb = Dp; a.strideB = (long)chunk * Dp; a.b_cols = Dp;
-            a.C = s->Jbuf; a.ldc = Dp; a.strideC = part;
-            a.M = 2 * ldn; a.N = (int)D + 1; a.K = chunk; a.nbatch = (int)S; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
-            RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
-            if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
-                a.A = d.OK + (long)S * chunk * a.lda; a.B = d.X + (long)S * chunk * Dp; a.K = rem; a.nbatch = 1; a.beta = 1.0;
+        for (int piece = 0; piece < npieces; ++piece) {
+            const double* Ap = d.OK + (long)piece * ldn;                 // columns [0, Mp) of Omega, then of Kappa
+            const long crow = (long)piece * ldn * Dp;                    // rows of the border: omega sums, then kappa sums
+            if (S >= 2) {
+                const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
+                PglGemmArgs a{};
+                a.A = Ap; a.lda = 2 * ldn; a.strideA = (long)chunk * a.lda; a.a_cols = Mp;
+                a.B = d.X; a.ldb = Dp; a.strideB = (long)chunk * Dp; a.b_cols = Dp;
+                a.C = s->Jbuf + crow; a.ldc = Dp; a.strideC = part;
+                a.M = Mp; a.N = (int)D + 1; a.K = chunk; a.nbatch = (int)S; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
                 RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
-            }
+                if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
+                    a.A = Ap + (long)S * chunk * a.lda; a.B = d.X + (long)S * chunk * Dp; a.K = rem; a.nbatch = 1; a.beta = 1.0;
+                    RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
+                }
+            } else RC(pgl_contract_tn(Ap, 2 * ldn, Mp, d.X, Dp, Dp, s->border + crow, Dp, Mp, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
+        }
+        if (S >= 2) {
             hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, s->Jbuf, part, (int)S, s->border, i > 0, Dp, (int)D + 1);
             PGL_CHECK_LAUNCH();
-        } else RC(pgl_contract_tn(d.OK, 2 * ldn, 2 * ldn, d.X, Dp, Dp, s->border, Dp, 2 * ldn, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
+        }
         clk.toc(m);
     }
     // ---- deterministic rows, status, optional log-odds record, block-prior constants
@@ -225,8 +237,8 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         c0 = s->c0_dense;
     }
 
-    for (int s0 = 0; s0 < nloc; s0 += nb) {
-        const int nbb = nb < nloc - s0 ? nb : nloc - s0;
+    for (int s0 = 0; s0 < nrun; s0 += nb) {
+        const int nbb = nb < nrun - s0 ? nb : nrun - s0;
         // ---- likelihood Gram of neurons [s0, s0 + nbb)  (regression.py:251-252)
         if (s->obs == 2) {
             auto m = clk.tic(ST_GSCALE, 8.0 * nbb * D * (D + 1) / 2);
@@ -252,12 +264,22 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
                     RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
                     clk.toc(m);
-                    m = clk.tic(ST_PLANES, (double)np * gz * d.T * D);
-                    RC(pgl_k_i8_planes(d.Xt, d.Tp, 1, om, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), d.T, (int)D, gz, np, st));   // (coalesced rows of Xt)
-                    clk.toc(m);
-                    m = clk.tic(ST_I8, (double)gz * d.T * D * (D + 1));
-                    RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), static_cast<const int8_t*>(s->i8_PB), static_cast<int8_t*>(s->i8_R), d.T, (int)D, gz, np, st));
-                    clk.toc(m);
+                    // time slices (BASELINE configs[4]: one neuron's planes are 86 GB): the integer Gram is a sum over time, so the
+                    // slices' products add up in the residues; a data set without resident X planes converts those per slice too
+                    const int slice = s->i8_slice > 0 && s->i8_slice < d.T ? s->i8_slice : d.T;
+                    for (int t0 = 0; t0 < d.T; t0 += slice) {
+                        const int ts = slice < d.T - t0 ? slice : d.T - t0;
+                        m = clk.tic(ST_PLANES, (double)np * (gz + (d.PA ? 0 : 1)) * ts * D);
+                        if (!d.PA) RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, nullptr, 0, d.sA, static_cast<int8_t*>(s->i8_PAs), ts, (int)D, 1, np, st));
+                        RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, om + (long)t0 * 2 * ldn, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), ts, (int)D, gz, np, st));   // (coalesced rows of Xt)
+                        clk.toc(m);
+                        m = clk.tic(ST_I8, (double)gz * ts * D * (D + 1));
+                        if (d.PA) RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), pgl_k_i8_kp(d.T), t0 / 64, static_cast<const int8_t*>(s->i8_PB),
+                                                   static_cast<int8_t*>(s->i8_R), ts, (int)D, gz, np, t0 > 0, st));
+                        else RC(pgl_k_i8_gram(static_cast<const int8_t*>(s->i8_PAs), 0, 0, static_cast<const int8_t*>(s->i8_PB), static_cast<int8_t*>(s->i8_R), ts,
+                                              (int)D, gz, np, t0 > 0, st));
+                        clk.toc(m);
+                    }
                     m = clk.tic(ST_CRT, (double)np * gz * D * (D + 1) / 2);
                     RC(pgl_k_i8_crt(static_cast<const int8_t*>(s->i8_R), d.sA, sB, s->Jbuf + (long)g0 * strideJ, ldj, strideJ, (int)D, gz, np, i > 0, st));
                     clk.toc(m);

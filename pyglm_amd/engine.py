@@ -124,7 +124,7 @@ class GibbsEngine(object):
         # the likelihood Gram X'OX: "fp64" = the fp64-MFMA kernel; "int8" = exact integer arithmetic on the int8 MFMA (residue planes +
         # CRT, pgl_i8_*; operands rounded to integers scaled from their column norms -- measured error several times below the fp64
         # kernel's own); "auto" (default) takes the integer path per data set where it is the faster one and its
-        # planes fit in memory (_use_int8)
+        # planes -- whole or in time slices -- fit in memory (_i8_plan)
         import os
         self.gram = gram or os.environ.get("PGL_GRAM", "auto")
         assert self.gram in ("auto", "fp64", "int8")
@@ -140,25 +140,21 @@ class GibbsEngine(object):
         # the compacted active block of the weight draw overlays the tableau, which is dead once a batch's flips are done (kept apart
         # with visit_order=False, where tests read the final tableau): two (D+2)^2 buffers per neuron instead of three
         self.share_tableau = self.visit_order
-        per_neuron = (2 if self.share_tableau else 3) * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
-        if batch is None:
-            free, _ = torch.cuda.mem_get_info(self.dev)
-            budget = mem_budget_bytes if mem_budget_bytes is not None else int(free * 0.45)
-            batch = max(2, min(self.nloc, budget // per_neuron))
-            # equal batches: every batch pays the same latency-bound steps (one workgroup per neuron in the proposal and solve kernels,
-            # ~100 panel launches of the Cholesky), so 1024 neurons go as 4 x 256, not as 3 x 295 + 139 -- or, before the overlay, 5 x 204 + 4
-            batch = -(-self.nloc // -(-self.nloc // batch))
-        self.nb = int(min(batch, self.nloc))
+        # neurons per batch: given, or chosen when the first data set is in place (_ensure_batch) -- what is left of the GPU then has to hold
+        # the batch's posterior systems AND, on the integer Gram path, the residue planes
+        self._batch_arg, self._mem_budget = batch, mem_budget_bytes
+        self.nb = None
         self.design_only = design_only
         self.likelihood_only = bool(likelihood_only)
         if likelihood_only:
             self._alloc_shard()
         elif not design_only:
-            self._alloc_batch()
             self._alloc_shard()
+            if batch is not None:
+                self._ensure_batch()
         self.keep_logodds = False       # True: sweep() leaves the flip log-odds in self.logodds (parity tests)
         self.logodds = None
-        self.profile = False
+        self.profile = False            # True: every stage of pgl_sweep is timed with HIP events; a collection of stage names: only those
         self._times = None              # pgl_stage_times_t filled by pgl_sweep while `profile` is on
         self._ev = []
 
@@ -202,6 +198,30 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ buffers
     def _z(self, *shape, dtype=F64):
         return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def _free_bytes(self):
+        """memory this engine may still take on its GPU.  Ranks that share one device (bench.py with PGL_BENCH_DEVICE: PGL_DEVICE_SHARE =
+        their number) each stay inside an equal share of it, whatever the others have allocated so far."""
+        import os
+        free, total = torch.cuda.mem_get_info(self.dev)
+        share = max(1, int(os.environ.get("PGL_DEVICE_SHARE", "1")))
+        if share > 1:
+            free = min(free, int(total * 0.94) // share - torch.cuda.memory_reserved(self.dev))
+        return max(0, free)
+
+    def _ensure_batch(self):
+        if self.nb is not None or self.design_only or self.likelihood_only:
+            return
+        batch = self._batch_arg
+        per_neuron = (2 if self.share_tableau else 3) * self.ldj * self.ldj * 8 + 2 * self.kmax * self.ldj * 8 + 2 * (self.kmax + 1) ** 2 * 8
+        if batch is None:
+            budget = self._mem_budget if self._mem_budget is not None else int(self._free_bytes() * 0.45)
+            batch = max(2, min(self.nloc, budget // per_neuron))
+            # equal batches: every batch pays the same latency-bound steps (one workgroup per neuron in the proposal and solve kernels,
+            # ~100 panel launches of the Cholesky), so 1024 neurons go as 4 x 256, not as 3 x 295 + 139 -- or, before the overlay, 5 x 204 + 4
+            batch = -(-self.nloc // -(-self.nloc // batch))
+        self.nb = int(min(batch, self.nloc))
+        self._alloc_batch()
 
     def _alloc_batch(self):
         nb, ldj, N, D, kmax = self.nb, self.ldj, self.N, self.D, self.kmax
@@ -278,6 +298,7 @@ class GibbsEngine(object):
             return ds
         ds.Y = self._z(T, self.ldn)
         ds.Y[:, :self.nloc] = torch.from_numpy(np.ascontiguousarray(Y[:, self.n0:self.n1])).to(self.dev)
+        self._ensure_batch()
         ds.Psi = self._z(T, self.ldn)
         if not self.likelihood_only:
             ds.OK = self._z(ds.Tp, 2 * self.ldn)      # [Omega | Kappa], rows >= T stay zero
@@ -287,20 +308,22 @@ class GibbsEngine(object):
             ds.X = ds.OK = None                   # the activation contraction reads X' only
             ds.int8 = False
             return ds
-        ds.int8 = self._use_int8(T)
+        plan = self._i8_plan(T)
+        ds.int8 = plan is not None
         if ds.int8:
-            # residue planes of X (once per data set), scaled column by column from the columns' norms and maxima
+            # residue planes of X, scaled column by column from the columns' norms and maxima: kept for the life of the data set where
+            # they fit (plan["resident"]), else converted slice by slice inside the sweep
             lib = _lib.load()
-            ds.planes = self.planes or lib.pgl_i8_min_planes(T)
-            if lib.pgl_i8_norm_bits(ds.planes, T) < 8:
-                raise ValueError("%d residue planes cannot hold T = %d time bins" % (ds.planes, T))
+            ds.planes = plan["planes"]
             stat = self._z(2, self.D)
             ds.sA = self._z(self.D)
             call("pgl_i8_colstats", ptr(ds.X), self.Dp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
             call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, ds.planes, ptr(ds.sA), st)
-            ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
-            call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
-            self._i8_reserve(T, ds.planes)
+            ds.PA = None
+            if plan["resident"]:
+                ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
+                call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
+            self._i8_reserve(T, plan)
             torch.cuda.synchronize(self.dev)
         if self.obs == 2:
             ones = self._z(ds.Tp, 2)
@@ -314,48 +337,83 @@ class GibbsEngine(object):
     I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
     I8_MIN_D, I8_MIN_T = 1024, 2048
 
-    def _i8_need(self, T, G, planes=None):
-        lib = _lib.load()
-        planes = planes or self.planes or lib.pgl_i8_min_planes(T)
-        return G * (lib.pgl_i8_plane_bytes(self.D, T) + lib.pgl_i8_residue_bytes(self.D)) // lib.pgl_i8_max_planes() * planes
-
-    def _use_int8(self, T):
-        """the Gram of a data set goes through the int8 MFMA if asked for, or (auto) if the shape is one where it is faster than the fp64
-        kernel (256 x 256 tiles, 15 planes: not for small D or short T) and X's planes plus one neuron's scratch fit beside everything else"""
-        if self.obs == 2 or self.design_only or self.likelihood_only or self.gram == "fp64":
-            return False
-        if self.gram == "int8":
-            return True
-        if self.D < self.I8_MIN_D or T < self.I8_MIN_T:
-            return False
-        free, _ = torch.cuda.mem_get_info(self.dev)
-        have = self._i8_scratch[0] if self._i8_scratch else 0
-        fits = _lib.load().pgl_i8_plane_bytes(self.D, T) + max(0, self._i8_need(T, 1) - have) < 0.8 * free
-        if not fits:
-            import warnings
-            warnings.warn("gram='auto': the residue planes of this data set (D = %d, T = %d) do not fit in the %.0f GB free on %s; its likelihood "
-                          "Gram runs on the fp64 MFMA kernel" % (self.D, T, free / 1e9, self.dev), RuntimeWarning, stacklevel=3)
-        return fits
-
-    def _i8_reserve(self, T, planes):
-        """scratch for the planes of omega_g X and the residues of a group of G neurons, sized for the largest data set seen so far
-        (planes and residues separately: a shorter data set may need more moduli, i.e. a larger residue buffer)"""
-        lib = _lib.load()
+    def _i8_plan(self, T):
+        """-> None (this data set's Gram runs on the fp64 kernel) or how it goes through the int8 MFMA: dict(planes, resident, G, slice).
+        The integer path is taken if asked for, or (auto) at shapes where it is the faster one (320 x 320 tiles, 13 planes: not for small D
+        or short T).  Memory decides the rest: X's planes stay resident if they are a small part of what is free; the planes of omega_g X
+        for a group of G <= 8 neurons and the group's residues must fit -- if a whole data set's do not (BASELINE configs[4]: 86 GB of
+        planes per neuron), the product runs in time slices that add up in the residues (pgl_sweep_t.i8_slice), and only if not even a
+        short slice fits does the data set fall back to the fp64 kernel (with a warning)."""
         import os
+        if self.obs == 2 or self.design_only or self.likelihood_only or self.gram == "fp64":
+            return None
+        if self.gram != "int8" and (self.D < self.I8_MIN_D or T < self.I8_MIN_T):
+            return None
+        lib = _lib.load()
+        planes = self.planes or lib.pgl_i8_min_planes(T)
+        if lib.pgl_i8_norm_bits(planes, T) < 8:
+            raise ValueError("%d residue planes cannot hold T = %d time bins" % (planes, T))
         mp = lib.pgl_i8_max_planes()
-        pb1, r1 = lib.pgl_i8_plane_bytes(self.D, T) // mp * planes, lib.pgl_i8_residue_bytes(self.D) // mp * planes
+        pa_full = lib.pgl_i8_plane_bytes(self.D, T) // mp * planes
+        kp_full = max(256, -(-T // 64) * 64)                     # bytes per plane row: the bins, padded to the 64-byte K tile
+        per_bin = planes * lib.pgl_i8_padded_rows(self.D)        # bytes of one time bin in one set of planes
+        r1 = lib.pgl_i8_residue_bytes(self.D) // mp * planes
+        free = self._free_bytes()
+        have = self._i8_scratch[0] if self._i8_scratch else 0
+        budget = int(0.85 * free) + have
+        gmax = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb or self.nloc)))
+        forced = os.environ.get("PGL_I8_SLICE")               # test / probe hook: time bins per slice
+        cands = []
+        keep = pa_full <= 0.3 * free and os.environ.get("PGL_I8_RESIDENT", "1") != "0"      # (PGL_I8_RESIDENT=0: test hook)
+        for resident in ((True, False) if keep else (False,)):
+            for G in (8, 4, 2, 1):
+                if G > gmax:
+                    continue
+                fixed = (pa_full if resident else 0) + G * r1
+                S = (budget - fixed) // (per_bin * (G + (0 if resident else 1)))
+                cands.append((resident, G, int(S)))
+        if forced:
+            S = max(64, int(forced) // 64 * 64)
+            return dict(planes=planes, resident=cands[0][0], G=min(gmax, 8), slice=S if S < T else 0)
+        for resident, G, S in cands:
+            if S >= kp_full:
+                return dict(planes=planes, resident=resident, G=G, slice=0)
+        cands = [c for c in cands if c[2] >= 16384]
+        if not cands:
+            import warnings
+            warnings.warn("gram='auto': not even a 16384-bin slice of the residue planes of this data set (D = %d, T = %d) fits in the %.0f GB free "
+                          "on %s; its likelihood Gram runs on the fp64 MFMA kernel" % (self.D, T, free / 1e9, self.dev), RuntimeWarning, stacklevel=3)
+            if self.gram == "int8":
+                raise _lib.PglError("gram='int8': the residue planes do not fit")
+            return None
+        resident, G, S = max(cands, key=lambda c: (min(c[2], kp_full // 2), c[1]))       # long slices first (at least two are needed anyway), then large groups
+        nsl = -(-T // (S // 1024 * 1024))
+        S = -(-(-(-T // nsl)) // 1024) * 1024                                             # equal slices, multiples of 1024 bins
+        return dict(planes=planes, resident=resident, G=G, slice=int(S))
+
+    def _i8_reserve(self, T, plan):
+        """scratch for the planes of omega_g X (one time slice of them) and the residues of a group of G neurons -- and for a slice of X's own
+        planes where those are not resident -- sized for the largest need seen so far"""
+        lib = _lib.load()
+        mp, planes = lib.pgl_i8_max_planes(), plan["planes"]
+        Ts = plan["slice"] or T
+        pb1, r1 = lib.pgl_i8_plane_bytes(self.D, Ts) // mp * planes, lib.pgl_i8_residue_bytes(self.D) // mp * planes
+        G, pas = plan["G"], (0 if plan["resident"] else pb1)
         if self._i8_scratch:
-            _, _, G, PB, R, _ = self._i8_scratch
-            if PB.numel() >= G * pb1 and R.numel() >= G * r1:
+            _, _, G0, PB, R, _, S0, PAs = self._i8_scratch
+            if G0 == G and S0 == plan["slice"] and PB.numel() >= G * pb1 and R.numel() >= G * r1 and (PAs.numel() if PAs is not None else 0) >= pas:
                 return
-            pb1, r1 = max(pb1, PB.numel() // G), max(r1, R.numel() // G)      # keep what earlier data sets need
+            if S0 != plan["slice"] and (S0 or plan["slice"]):
+                raise _lib.PglError("data sets with different time slicing of the integer Gram in one engine (add the largest first)")
+            pb1, r1 = max(pb1, PB.numel() // G0), max(r1, R.numel() // G0)      # keep what earlier data sets need
+            pas = max(pas, PAs.numel() if PAs is not None else 0)
+            G = min(G, G0)
         self._i8_scratch = None
         torch.cuda.empty_cache()
-        free, _ = torch.cuda.mem_get_info(self.dev)
-        G = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb, (free * 0.85) // (pb1 + r1))))
-        self._i8_scratch = (G * (pb1 + r1), T, G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
+        self._i8_scratch = (G * (pb1 + r1) + pas, T, G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
                             torch.empty(G * r1, dtype=torch.int8, device=self.dev),
-                            self._z(3, G, self.D))          # per group: column maxima, sums of squares, scales of omega_g X
+                            self._z(3, G, self.D),          # per group: column maxima, sums of squares, scales of omega_g X
+                            plan["slice"], torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None)
 
     @_on_device
     def drop_int8(self, i):
@@ -365,6 +423,8 @@ class GibbsEngine(object):
         if ds.int8:
             ds.int8 = False
             ds.PA = ds.sA = None
+            if not any(getattr(d, "int8", False) for d in self.datasets):
+                self._i8_scratch = None             # nobody multiplies planes any more: the group buffers (56 GB at cfg3) go back too
             torch.cuda.empty_cache()
 
     @_on_device
@@ -440,16 +500,19 @@ class GibbsEngine(object):
 
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
     @_on_device
-    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None):
+    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None, nrun=0):
         """regression.py:265-280 for every local neuron, as ONE call of pgl_sweep (include/pyglm_hip.h): the whole sweep is queued on the
         stream without a host synchronisation.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in natural form
         (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
         omega_override: list of (T, nloc) arrays replacing the PG draws (test hook: the reference fixtures inject omega).
         host_overlap: optional callable run on the host while the GPU works through the queue (seconds at full size), e.g. to draw the
-        next sweep's permutations."""
+        next sweep's permutations.
+        nrun: sweep only the first nrun local neurons (what one rank of a larger job would do, timed on this GPU -- bench.py's
+        scaling_proxy); the returned rows of the others are their input."""
         nloc, N, B, D = self.nloc, self.N, self.B, self.D
         if self.likelihood_only or self.design_only:
             raise _lib.PglError("this engine was built without sweep buffers (likelihood_only / design_only)")
+        self._ensure_batch()
         st = self._st()
         a = np.asarray(a).astype(bool)
         rho = np.asarray(rho, dtype=np.float64)
@@ -482,6 +545,10 @@ class GibbsEngine(object):
         i8 = self._i8_scratch
         if self.profile and self._times is None:
             self._times = _lib.StageTimes()
+            if self.profile is not True:
+                lib = _lib.load()
+                names = [lib.pgl_stage_name(i).decode() for i in range(_lib.NSTAGES)]
+                self._times.mask = sum(1 << names.index(n) for n in self.profile)
         n_act = int(a.sum(axis=1).max()) if a.size else 0
         sw = _lib.Sweep(N, B, self.n0, nloc, self.nb, self.obs, self.xi, int(self.visit_order), self.planes or 0, i8[2] if i8 else 0,
                         dsets, len(self.datasets), ptr(self.a_dev), ptr(self.W_dev), ptr(self.b_dev),
@@ -492,6 +559,7 @@ class GibbsEngine(object):
                         ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
                         ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
                         ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
+                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, int(nrun),
                         int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
                         ctypes.pointer(self._times) if self.profile else None)
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
@@ -533,16 +601,28 @@ class GibbsEngine(object):
 
     def _i8_group(self, ds, om, ldo, gz, Jp, accumulate):
         """J[g] (+)= X' diag(om[:, g]) X for gz <= group size weight columns at `om` (device pointer, leading dimension ldo): column
-        statistics -> scales -> residue planes -> int8 products mod p -> CRT"""
+        statistics -> scales -> per time slice: residue planes -> int8 products mod p (added up in the residues) -> CRT"""
         D, Dp, ldj = self.D, self.Dp, self.ldj
         st = self._st()
-        _, _, G, PB, R, stat = self._i8_scratch
+        _, _, G, PB, R, stat, S, PAs = self._i8_scratch
         assert gz <= G
         npl = ds.planes
         call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
-        call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
-        call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)
+        if not S and ds.PA is not None:
+            call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
+            call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)
+        else:
+            S = S or ds.T
+            for t0 in range(0, ds.T, S):
+                ts = min(S, ds.T - t0)
+                xt = ctypes.c_void_p(ds.Xt.data_ptr() + 8 * t0)
+                omt = ctypes.c_void_p(om.value + 8 * t0 * ldo)
+                if ds.PA is None:
+                    call("pgl_i8_planes_t", xt, ds.Tp, None, 0, ptr(ds.sA), ptr(PAs), ts, D, 1, npl, st)
+                call("pgl_i8_planes_t", xt, ds.Tp, omt, ldo, ptr(stat[2]), ptr(PB), ts, D, gz, npl, st)
+                call("pgl_i8_gram_slice", ptr(ds.PA) if ds.PA is not None else ptr(PAs), ds.T if ds.PA is not None else 0, t0, ptr(PB), ptr(R), ts, ds.T,
+                     D, gz, npl, int(t0 > 0), st)
         call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), Jp, ldj, ldj * ldj, ds.T, D, gz, npl, accumulate, st)
 
     # test hooks --------------------------------------------------------------------------------------------------

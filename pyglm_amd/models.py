@@ -38,7 +38,7 @@ class NonlinearAutoregressiveModel(object):
     """(models.py:8-201) y_n[t] ~ p(f(w_n . x[t])), x = basis-filtered history of all neurons."""
     DRAW_AHEAD_MIN_SIZE = 1 << 16      # N*N*B above which the next sweep's host draws are made while the GPU is busy
 
-    def __init__(self, N, regressions, basis=None, B=10, device=None, engine_factory=None, seed=None, engine_kwargs=None):
+    def __init__(self, N, regressions, basis=None, B=10, device=None, engine_factory=None, seed=None, engine_kwargs=None, shard=None):
         self.N = N
         assert len(regressions) == N
         self.regressions = regressions
@@ -54,6 +54,12 @@ class NonlinearAutoregressiveModel(object):
         self.world = dist.get_world_size() if dist else 1
         self.rank = dist.get_rank() if dist else 0
         self.n0, self.n1 = shard_bounds(N, self.world, self.rank)
+        # shard=(n0, n1): this process sweeps neurons [n0, n1) only, whatever the process group says, and exchanges nothing -- the other
+        # rows of (A, W, b) keep their values.  What ONE rank of a job too large for the GPUs at hand does (bench.py --neurons).
+        self._shard_override = shard is not None
+        if shard is not None:
+            self.n0, self.n1 = int(shard[0]), int(shard[1])
+            assert 0 <= self.n0 < self.n1 <= N
         self._device = device
         self._engine_factory = engine_factory
         self._engine_kwargs = engine_kwargs or {}
@@ -138,7 +144,7 @@ class NonlinearAutoregressiveModel(object):
     def _gather_rows(self, arr):
         """all_gather of per-neuron rows over the shard axis (ranks may own different counts)"""
         dist = _dist()
-        if dist is None:
+        if dist is None or self._shard_override:
             return arr
         import time
         import torch
@@ -253,8 +259,8 @@ class NonlinearAutoregressiveModel(object):
     def resample_model(self):
         self.resample_regressions()
 
-    def resample_regressions(self):
-        """(models.py:169-171) all local neurons through the GPU engine, then an all_gather of the new rows."""
+    def _sweep_inputs(self):
+        """everything engine.sweep needs for the shard at the current chain state: (a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z)"""
         from .engine import make_draws, prior_terms
         regs = self.regressions[self.n0:self.n1]
         a, W, b = self._local_state()
@@ -279,6 +285,13 @@ class NonlinearAutoregressiveModel(object):
             perm, u, z = pre[1]
         else:
             perm, u, z = make_draws(self.seed, self.sweeps_done, range(self.n0, self.n1), self.N, self.N * self.B)
+        return a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z
+
+    def resample_regressions(self):
+        """(models.py:169-171) all local neurons through the GPU engine, then an all_gather of the new rows."""
+        from .engine import make_draws
+        regs = self.regressions[self.n0:self.n1]
+        a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z = self._sweep_inputs()
         self._draws_ahead = None
 
         def draw_ahead():
@@ -299,8 +312,14 @@ class NonlinearAutoregressiveModel(object):
             for i, r in enumerate(regs):
                 alpha, beta = r.eta_posterior(T_total, sse[i])
                 eta[i] = 1.0 / (make_gamma_draws(self.seed, self.sweeps_done, [self.n0 + i], alpha)[0] * (1.0 / beta))
-            eta_all = self._gather_rows(eta)
+            eta_all = eta if self._shard_override else self._gather_rows(eta)
         self.sweeps_done += 1
+        if self._shard_override:
+            for i, r in enumerate(regs):
+                r.a, r.W, r.b = a[i].copy(), W[i].copy(), b[i:i + 1].copy()
+                if gaussian:
+                    r.eta = float(eta[i])
+            return
         A_all = self._gather_rows(a)
         W_all = self._gather_rows(W)
         b_all = self._gather_rows(b)

@@ -32,15 +32,26 @@ class _SparseScalarRegressionBase(object):
     def __init__(self, N, B, rho=0.5, mu_w=0.0, S_w=1.0, mu_b=0.0, S_b=1.0):
         self.N, self.B = N, B
         self.rho, self.mu_w, self.mu_b, self.S_w, self.S_b = rho, mu_w, mu_b, S_w, S_b
-        # initial state: a draw from the prior, same NumPy calls as the reference (:86-92)
+        # initial state: a draw from the prior, the reference's own NumPy stream (:86-92) at every N: `npr.rand(N)`, then one
+        # `npr.multivariate_normal(mu_w[n], S_w[n])` per presynaptic neuron -- which is standard_normal(B) pushed through the SVD factor of
+        # the covariance (numpy/random/mtrand: x . (sqrt(s)[:, None] v) + mean).  The normals of all N calls are one standard_normal((N, B))
+        # (the legacy generator fills an array by the same successive draws), the factor is formed once per DISTINCT covariance instead of
+        # a million times at N = 1024, and the per-row product is the same 1-D np.dot: same seed -> the same initial chain as the
+        # reference, bit for bit (fixture G13, tests/test_host_logic.py).
         self.a = npr.rand(N) < self.rho
         self.W = np.zeros((N, B))
-        if N <= 256:
-            for n in range(N):
-                self.W[n] = self.a[n] * npr.multivariate_normal(self.mu_w[n], self.S_w[n])
-        else:   # same law, vectorised (a million multivariate_normal calls at N = 1024 would take a minute)
-            L = np.linalg.cholesky(self.S_w)
-            self.W = self.a[:, None] * (self.mu_w + np.einsum("nij,nj->ni", L, npr.randn(N, B)))
+        Z = npr.standard_normal((N, B))
+        factors = {}
+        S_all, mu_all = self._get_rows("_S_w"), self._get_rows("_mu_w")
+        for n in np.nonzero(self.a)[0]:
+            key = S_all[n].tobytes()
+            M = factors.get(key)
+            if M is None:
+                _, sv, v = np.linalg.svd(S_all[n])
+                M = factors[key] = np.sqrt(sv)[:, None] * v
+            x = np.dot(Z[n], M)
+            x += mu_all[n]
+            self.W[n] = x
         self.b = npr.multivariate_normal(self.mu_b, self.S_b)
         self._engine_cache = None
         self._lik_engine_cache = None

@@ -315,6 +315,15 @@ def main():
     net = FixedMeanSparseNetwork(3, 2, mu=0.7, sigma=4.0, rho=0.3)
     out["N_fixed_mu"], out["N_fixed_sigma"], out["N_fixed_rho"] = np.array(net.mu_W), np.array(net.sigma_W), np.array(net.rho)
 
+    # G13: the initial state a regression draws from its prior under a NumPy seed (regression.py:86-92: rand(N), then one
+    # multivariate_normal per presynaptic neuron, then the bias), at a size above and below where a vectorised draw would be tempting
+    from pyglm.regression import SparseBernoulliRegression
+    for tag, (N_, B_, kw_) in {"small": (7, 3, dict(rho=0.6, S_w=2.0, mu_w=0.3, mu_b=-1.0, S_b=0.5)),
+                               "large": (300, 2, dict(rho=0.5, S_w=10.0, mu_b=-2.0))}.items():
+        np.random.seed(1234)
+        r_ = SparseBernoulliRegression(N_, B_, **kw_)
+        out["I_%s_a" % tag], out["I_%s_W" % tag], out["I_%s_b" % tag] = np.array(r_.a), np.array(r_.W), np.array(r_.b)
+
     path = os.path.join(OUT, "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%d arrays, %.1f KB" % (len(out), os.path.getsize(path) / 1024))

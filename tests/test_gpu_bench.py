@@ -1,0 +1,42 @@
+"""bench.py's own launch path: `python bench.py --gpus N` with no launcher around it starts N ranks itself (bench.py::self_launch).  On a
+one-GPU box the ranks share the device (PGL_BENCH_DEVICE=0) and talk over gloo (RCCL refuses two ranks on one device); sharding
+(models.py:169-171 by postsynaptic neuron), the all_gather of the rows, the scalar all_reduce and the max-over-ranks timing are the real
+ones."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(gpus, *extra):
+    env = dict(os.environ, PGL_BENCH_DEVICE="0", PGL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--config", "cfg2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-fp64-compare", "--no-scaling-proxy"] + list(extra)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout (rank 0): %r" % p.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_equals_one_rank():
+    one = _bench(1)
+    two = _bench(2)
+    for d, n in ((one, 1), (two, 2)):
+        assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "sweeps/s" and d["value"] > 0
+        assert abs(d["value"] - 2 / (d["ms_per_step"] * 2e-3)) < 1e-9 * d["value"]
+        assert len(d["per_rank"]) == n and sorted(r["rank"] for r in d["per_rank"]) == list(range(n))
+        assert sum(r["neurons"] for r in d["per_rank"]) == 128
+        assert d["roofline"]["achieved"] > 0 and d["roofline"]["unit"] == "TFLOP/s"
+    assert two["per_rank"][0]["collectives_ms_per_step"] > 0
+    # the chain does not depend on the number of ranks (random inputs are keyed by the global neuron); the log-likelihood is a sum of
+    # per-rank partial sums (one all_reduce), so it agrees to rounding of the summation order, not to the bit
+    a, b = one["log_likelihood_after"], two["log_likelihood_after"]
+    assert abs(a - b) <= 1e-12 * abs(a)

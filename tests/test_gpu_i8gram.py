@@ -353,6 +353,43 @@ def test_sweep_with_integer_gram_equals_fp64_sweep_and_oracle(N, B, T, batch):
         np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
+    """BASELINE configs[4] cannot hold a neuron's planes at once: the integer Gram then runs in time slices whose products add up in the
+    residues (pgl_i8_gram_slice), with X's planes either resident or converted per slice.  The arithmetic is exact, so J and the whole
+    sweep must come out bit for bit as without slices -- including a last slice that is shorter and one that is not a multiple of 64."""
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    rng = np.random.default_rng(11)
+    N, B, T = 70, 5, 2300
+    D = N * B
+    Y = (rng.random((T, N)) < 0.1).astype(float)
+    X = rng.random((T, N, B)) * (rng.random((T, N, B)) < 0.3) * 0.2
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
+    b = np.full(N, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * 4.0, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+    rho = np.full((N, N), 0.5)
+    perm, u, z = make_draws(5, 0, range(N), N, D)
+    res = []
+    for slc in (None, "640", "1024"):
+        if slc is None:
+            monkeypatch.delenv("PGL_I8_SLICE", raising=False)
+            monkeypatch.delenv("PGL_I8_RESIDENT", raising=False)
+        else:
+            monkeypatch.setenv("PGL_I8_SLICE", slc)
+            monkeypatch.setenv("PGL_I8_RESIDENT", resident)
+        eng = GibbsEngine(N, B, gram="int8", batch=N)
+        ds = eng.add_data(Y, X=X)
+        assert ds.int8 and (eng._i8_scratch[6] == (int(slc) if slc else 0)) and ((ds.PA is None) == (slc is not None and resident == "0"))
+        out = eng.sweep(a, W, b, rho, *hyp, perm, u, z, seed=5, sweep=0)
+        res.append((eng.Jbuf[:, :D + 2, :D + 2].cpu().numpy().copy(), out))
+        del eng
+    for J, out in res[1:]:
+        np.testing.assert_array_equal(np.tril(J), np.tril(res[0][0]))
+        for x, y in zip(out, res[0][1]):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_auto_takes_the_integer_gram_where_it_pays():
     """gram='auto' (the default): int8 planes for large D and long T, the fp64 kernel for small shapes and for the Gaussian model"""
     from pyglm_amd.engine import GibbsEngine

@@ -522,3 +522,67 @@ def test_mixed_deterministic_and_sampled_rows_in_one_batch(torch_dev):
         np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(b1[n], r.b[0], rtol=1e-7, atol=1e-9)
     assert a1[2].all() and not a1[9].any() and np.array_equal(a1[5], rho[5].astype(bool))
+
+
+@pytest.mark.parametrize("batch", [2, 12])
+def test_split_border_contraction_two_datasets_nan_scratch(torch_dev, batch):
+    """the border sums [Omega|Kappa]'[X, 1] (regression.py:253-260) are split over time slices whose partial sums pass through the batch's
+    J buffer (pgl_sweep.hip): several slices with a ragged tail (Tp is not a multiple of 16 S), a second data set that accumulates, a
+    small batch so that the buffer caps the number of slices -- with J and the tableau pre-filled with NaN, which must not leak into
+    the border, the posterior or the draw."""
+    import torch
+    from pyglm_amd.engine import make_draws
+    rng = np.random.default_rng(17)
+    N, B = 12, 2
+    Ts = [2500, 1310]
+    Xs = [np.abs(rng.standard_normal((T, N, B))) * 0.4 for T in Ts]
+    Ys = [(rng.random((T, N)) < 0.3).astype(float) for T in Ts]
+    kw = dict(rho=0.5, S_w=2.0, mu_w=0.1, mu_b=-0.5, S_b=1.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.5 * a[:, :, None]
+    b = rng.standard_normal(N) * 0.3
+    eng = _engine(N, B, batch=batch)
+    for X, Y in zip(Xs, Ys):
+        eng.add_data(Y, X=X)
+    eng.Jbuf.fill_(float("nan"))
+    eng.Mtab.fill_(float("nan"))
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    hyp = _hyp(regs)
+    perm, u, z = make_draws(5, 3, range(N), N, N * B)
+    a1, W1, b1, ll = eng.sweep(a, W, b, *hyp, perm, u, z, seed=5, sweep=3)
+    D = N * B
+    want = sum(ds.OK[:ds.Tp].T.double() @ ds.X[:ds.Tp] for ds in eng.datasets)          # (2 ldn, Dp), rows = omega sums then kappa sums
+    got = eng.border
+    np.testing.assert_allclose(got[:, :D + 1].cpu().numpy(), want[:, :D + 1].cpu().numpy(), rtol=1e-12, atol=1e-12)
+    assert np.isfinite(W1).all() and np.isfinite(b1).all()
+    oms = [ds.OK[:ds.T, :N].cpu().numpy() for ds in eng.datasets]
+    for n in range(N):
+        r = orc.Regression(N, B, **kw)
+        r.a, r.W, r.b = a[n].copy(), W[n].copy(), b[n:n + 1].copy()
+        r.resample([(X, Y[:, n]) for X, Y in zip(Xs, Ys)], [om[:, n] for om in oms], perm[n], u[n], z[n])
+        np.testing.assert_array_equal(a1[n], r.a)
+        np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("gram", ["fp64", "int8"])
+def test_prefix_run_equals_the_same_neurons_of_a_full_sweep(torch_dev, gram):
+    """engine.sweep(nrun=k) -- what bench.py's scaling_proxy times: one rank's share of a larger job -- sweeps the first k local neurons
+    exactly as the full sweep does (bit for bit) and leaves the others as they came in"""
+    from pyglm_amd.engine import make_draws
+    N, B, T = 13, 2, 700
+    basis, X, Y, rng = _random_problem(N, B, T, seed=8)
+    kw = dict(rho=0.4, S_w=3.0, mu_w=0.0, mu_b=-1.0, S_b=1.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * a[:, :, None]
+    b = rng.standard_normal(N)
+    hyp = _hyp([orc.Regression(N, B, **kw) for _ in range(N)])
+    perm, u, z = make_draws(9, 2, range(N), N, N * B)
+    eng = _engine(N, B, gram=gram, batch=4)
+    eng.add_data(Y, basis=basis)
+    full = eng.sweep(a, W, b, *hyp, perm, u, z, seed=9, sweep=2)
+    for k in (5, 8):
+        part = eng.sweep(a, W, b, *hyp, perm, u, z, seed=9, sweep=2, nrun=k)
+        for x, y, x0 in zip(part[:3], full[:3], (a, W, b)):
+            np.testing.assert_array_equal(x[:k], y[:k])
+            np.testing.assert_array_equal(x[k:], x0[k:])
+        np.testing.assert_array_equal(part[3][:k], full[3][:k])

@@ -406,3 +406,17 @@ def test_chain_state_roundtrip_resumes_exactly():
         np.testing.assert_array_equal(m.weights, first[1])
         np.testing.assert_array_equal(m.biases, first[2])
         assert m.log_likelihood() == first[3]
+
+
+def test_initial_state_is_the_references_draw_at_every_size(golden):
+    """regression.py:86-92 draws a, W, b from the prior with NumPy's global generator; fixture G13 holds what the REFERENCE drew under
+    np.random.seed(1234) for N = 7 and N = 300.  Same seed -> the same initial chain, bit for
+    bit, at the benchmark sizes too (round 2 switched to a vectorised draw above N = 256, which was a different stream)."""
+    from pyglm_amd.regression import SparseBernoulliRegression
+    for tag, (N, B, kw) in {"small": (7, 3, dict(rho=0.6, S_w=2.0, mu_w=0.3, mu_b=-1.0, S_b=0.5)),
+                            "large": (300, 2, dict(rho=0.5, S_w=10.0, mu_b=-2.0))}.items():
+        np.random.seed(1234)
+        r = SparseBernoulliRegression(N, B, **kw)
+        np.testing.assert_array_equal(r.a, golden["I_%s_a" % tag])
+        np.testing.assert_array_equal(r.W, golden["I_%s_W" % tag])
+        np.testing.assert_array_equal(np.asarray(r.b), golden["I_%s_b" % tag])

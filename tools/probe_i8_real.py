@@ -24,7 +24,7 @@ eng._upload_weights(np.ones((nl, N), bool), rng.standard_normal((nl, N, B)) * 0.
 with torch.cuda.device(eng.dev):
     eng._psi_pass(True, 3, 0)
     D, Dp, ldj = eng.D, eng.Dp, eng.ldj
-    _, _, G, PB, R, stat = eng._i8_scratch
+    _, _, G, PB, R, stat = eng._i8_scratch[:6]
     om = ctypes.c_void_p(ds.OK.data_ptr())
     ldo = 2 * eng.ldn
     J = eng.Jslots[0]

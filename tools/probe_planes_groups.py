@@ -17,7 +17,7 @@ eng._upload_weights(np.ones((nl, N), bool), rng.standard_normal((nl, N, B)) * 0.
 with torch.cuda.device(eng.dev):
     eng._psi_pass(True, 3, 0)
     D, Dp = eng.D, eng.Dp
-    _, _, G, PB, R, stat = eng._i8_scratch
+    _, _, G, PB, R, stat = eng._i8_scratch[:6]
     ldo = 2 * eng.ldn
     call("pgl_i8_colstats", ptr(ds.X), Dp, ptr(ds.OK), ldo, T, D, nl, ptr(stat[0]), ptr(stat[1]), None)
     call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), nl * D, T, k, ptr(stat[2]), None)
