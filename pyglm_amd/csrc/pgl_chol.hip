@@ -5,7 +5,13 @@
 // Steps here: (1) compact the active sub-block (upper triangle) into Ac; (2) blocked right-looking Cholesky in the
 // UPPER form Ac = U'U (U = L'), so every panel U[q0:q0+64, :] is k-major and feeds the fp64 MFMA contraction directly:
 // the 64 x 64 diagonal factor and its inverse are formed in LDS, the row-panel solve U12 = U11^-T A12 and the rank-64 /
-// rank-128 updates of the trailing matrix run on pgl_gemm.hip; (3) U'w = h, U mu = w, U x = z;  out = mu + x.
+// rank-256 updates of the trailing matrix run on pgl_gemm.hip; (3) U'w = h, U (mu + x) = w + z;  out = mu + x.
+// The forward solve costs nothing of its own: h rides along as column na of the compact block (the system is factored as if it were
+// (na + 1)-dimensional, the last "pivot" never taken), so every panel solve and trailing update carries it and the column ends up
+// holding w.  The backward solve is one small launch per 64-row panel, from the last: every workgroup solves the panel's diagonal block
+// for itself and then subtracts the panel's contribution from its own rows above -- the rows are independent, so a neuron's solve
+// spreads over as many workgroups as it has rows / 256, and U streams through once.  (One workgroup per neuron doing all of it took
+// 34 ms per batch at cfg3 and over a second per batch at the 32 769-dim systems of configs[4].)
 #include "pgl_common.h"
 
 namespace {
@@ -70,7 +76,9 @@ __global__ __launch_bounds__(256) void gather_active_kernel(CholArgs g) {
         const int i = i0 + ii;
         if (i < na && j < na && j >= i) Ac[(long)i * g.ldc + j] = t[lane][ii];
     }
-    if (i0 == j0 && threadIdx.x < 64 && gi >= 0) g.hc[(long)n * g.ldc + i0 + lane] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
+    // h_active rides along as column na (rows < na); the corner (na, na) is never a pivot
+    if (i0 == j0 && threadIdx.x < 64 && gi >= 0) Ac[(long)(i0 + lane) * g.ldc + na] = J[(long)(g.N * g.B + 1) * g.ldj + gi];
+    if (i0 == 0 && j0 == 0 && threadIdx.x == 0) Ac[(long)na * g.ldc + na] = 0.0;
 }
 
 // factor the 64x64 diagonal block at q0: A11 = U11' U11, U11 written to the upper triangle in place
@@ -101,6 +109,17 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(CholArgs g, int q0) {
     }
     for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (i <= j) Ag[(long)i * g.ldc + j] = A[j][i]; }
     if (tid == 0 && s_bad) atomicOr(&g.status[n], 4);
+    // the neuron's last block, not a full one: column na (the h column) lies inside it, where no panel solve reaches -- L w = h here
+    // (one wave: unknown j per lane, a step is a broadcast and one multiply-add)
+    if (q0 + nb == na && nb < NBC && tid < 64) {
+        double* hcol = g.Ac + (long)n * g.strideC + (long)q0 * g.ldc + na;
+        double v = tid < nb ? hcol[(long)tid * g.ldc] : 0.0;
+        for (int j = 0; j < nb; ++j) {
+            const double wj = __shfl(v, j) / A[j][j];
+            if (tid == j) v = wj; else if (tid > j && tid < nb) v -= A[tid][j] * wj;
+        }
+        if (tid < nb) hcol[(long)tid * g.ldc] = v;
+    }
     // inverse of the lower factor, one column per thread (forward substitution on e_j); the row-panel solve
     // U12 = U11^-T A12 = L^-1 A12 then runs on the MFMA contraction with Tinv[k][m] = (L^-1)[m][k] as its k-major operand
     __shared__ double Li[NBC][NBC + 1];
@@ -121,112 +140,80 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(CholArgs g, int q0) {
     for (int e = tid; e < NBC * NBC; e += 256) { const int k = e / NBC, m = e % NBC; Tn[e] = Li[m][k]; }
 }
 
-// one workgroup per neuron:  U'w = h, then U mu = w and U x = z; scatter mu + x.  Blocked by 64 rows: the 64 x 64 diagonal block is solved
-// by one wave out of LDS (the unknowns live one per lane, a step is a shuffle and one multiply-add), the rest of the 64-row panel is
-// streamed once -- forward as a column-parallel update of the remaining right-hand side, backward as row dot products over 64 x 64
-// tiles staged through LDS, one tile per wave -- with two workgroup barriers per panel instead of two per row.
-__global__ __launch_bounds__(256) void solve_sample_kernel(CholArgs g) {
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// r = w + z: w from column na of the factored block, z the standard normals (U (mu + x) = w + z gives the draw in one solve)
+__global__ __launch_bounds__(256) void backsolve_init_kernel(CholArgs g) {
+    const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int na = g.na[n];
+    if (i >= na) return;
+    g.hc[(long)n * g.ldc + i] = g.Ac[(long)n * g.strideC + (long)i * g.ldc + na] + g.z[(long)n * g.ldz + i];
+}
+
+// panel pi (rows p0 = 64 pi .. p0 + pw) of U v = r, from the last panel: v_p = U_pp^-1 r_p by every workgroup for itself (one wave, in
+// LDS), then r[row] -= U[row][p0 .. p0 + pw) . v_p for the workgroup's rows above the panel.  Solved values go to the second plane of hc
+// (nobody writes the panel's own rows of r in this launch, so the redundant solves all read the same numbers).
+constexpr int BS_ROWS = 256;
+__global__ __launch_bounds__(256) void backsolve_panel_kernel(CholArgs g, int pi, long plane) {
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = g.na[n];
+    const int p0 = pi * NBC;
+    if (p0 >= na) return;
+    const int pw = min(NBC, na - p0);
+    const int r0 = blockIdx.x * BS_ROWS;
+    if (r0 >= p0 && blockIdx.x > 0) return;                 // no rows of this workgroup above the panel (workgroup 0 still publishes v_p)
     const double* U = g.Ac + (long)n * g.strideC;
     const long ld = g.ldc;
-    double* h = g.hc + (long)n * g.ldc;            // becomes w, then mu
-    double* xz = h + (long)gridDim.x * g.ldc;      // second plane of hc: z -> x
-    const double* z = g.z + (long)n * g.ldz;
-    __shared__ double Ud[NBC][NBC + 1];            // diagonal block
-    __shared__ double wp[2][NBC];                  // the panel's solved unknowns (two right-hand sides backward)
-    __shared__ double tile[4][NBC / 2][NBC + 1];   // backward: 32 x 64 half tiles of the panel, one per wave at a time
-    __shared__ double part[4][2][NBC];
-    for (int i = tid; i < na; i += 256) xz[i] = z[i];
+    double* r = g.hc + (long)n * g.ldc;
+    double* v = r + plane;
+    __shared__ double Ud[NBC][NBC + 1];
+    __shared__ double vp[NBC];
+    for (int e = tid; e < NBC * NBC; e += 256) {
+        const int i = e >> 6, c = e & 63;
+        Ud[i][c] = (i < pw && c < pw && c >= i) ? U[(long)(p0 + i) * ld + p0 + c] : (i == c ? 1.0 : 0.0);
+    }
     __syncthreads();
-    // ---- forward  U'w = h: panel p0: solve the diagonal block (w_j = h_j / U_jj; h_c -= U_jc w_j), then h[c] -= sum_j U[p0+j][c] w_j for c beyond
-    for (int p0 = 0; p0 < na; p0 += NBC) {
-        const int pw = min(NBC, na - p0);
-        for (int e = tid; e < NBC * NBC; e += 256) {
-            const int r = e >> 6, c = e & 63;
-            Ud[r][c] = (r < pw && c < pw && c >= r) ? U[(long)(p0 + r) * ld + p0 + c] : (r == c ? 1.0 : 0.0);
+    if (wave == 0) {
+        double x = lane < pw ? r[p0 + lane] : 0.0;
+        for (int i = pw - 1; i >= 0; --i) {
+            const double xi = __shfl(x, i) / Ud[i][i];
+            if (lane == i) x = xi; else if (lane < i) x -= Ud[lane][i] * xi;
         }
-        __syncthreads();
-        if (wave == 0) {
-            double v = lane < pw ? h[p0 + lane] : 0.0;
-            for (int j = 0; j < pw; ++j) {
-                const double wj = __shfl(v, j) / Ud[j][j];
-                if (lane == j) v = wj; else if (lane > j) v -= Ud[j][lane] * wj;
-            }
-            wp[0][lane] = v;
-            if (lane < pw) h[p0 + lane] = v;
-        }
-        __syncthreads();
-        // 32 independent row loads per column in flight (the kernel has four waves per CU: latency is hidden by depth, not by occupancy);
-        // rows past the end of a short last panel are clamped and meet wp = 0
-        for (int c = p0 + pw + tid; c < na; c += 256) {
-            double acc = 0.0;
-#pragma unroll
-            for (int jb = 0; jb < NBC; jb += 32) {
-                double u[32];
-#pragma unroll
-                for (int j = 0; j < 32; ++j) u[j] = U[(long)min(p0 + jb + j, na - 1) * ld + c];
-#pragma unroll
-                for (int j = 0; j < 32; ++j) acc += u[j] * wp[0][jb + j];
-            }
-            h[c] -= acc;
-        }
-        __syncthreads();
+        vp[lane] = lane < pw ? x : 0.0;
+        if (blockIdx.x == 0 && lane < pw) v[p0 + lane] = x;
     }
-    // ---- backward  U mu = w, U x = z (two right-hand sides): panels from the last; s_r = sum_{c beyond the panel} U[r][c] v[c] by tiles
-    const int np = (na + NBC - 1) / NBC;
-    for (int pi = np - 1; pi >= 0; --pi) {
-        const int p0 = pi * NBC, pw = min(NBC, na - p0);
-        double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;   // lane r < 32 of every wave: partial sums of rows p0 + r and p0 + 32 + r
-        for (int c0 = p0 + NBC + wave * NBC; c0 < na; c0 += 4 * NBC) {
-            const int cw = min(NBC, na - c0);
-            const double v1 = lane < cw ? h[c0 + lane] : 0.0, v2 = lane < cw ? xz[c0 + lane] : 0.0;
-#pragma unroll
-            for (int rh = 0; rh < NBC; rh += NBC / 2) {
-                for (int r = 0; r < NBC / 2; ++r)
-                    tile[wave][r][lane] = (rh + r < pw && lane < cw) ? U[(long)(p0 + rh + r) * ld + c0 + lane] : 0.0;   // coalesced rows
-                __builtin_amdgcn_wave_barrier();        // one wave = one instruction stream: its LDS writes are visible to its reads
-                double t1 = 0.0, t2 = 0.0;
-#pragma unroll 8
-                for (int c = 0; c < NBC; ++c) {
-                    const double u = tile[wave][lane & 31][c];
-                    t1 += u * __shfl(v1, c);
-                    t2 += u * __shfl(v2, c);
-                }
-                if (rh == 0) { sa1 += t1; sa2 += t2; } else { sb1 += t1; sb2 += t2; }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (lane < 32) {
-            part[wave][0][lane] = sa1; part[wave][1][lane] = sa2;
-            part[wave][0][32 + lane] = sb1; part[wave][1][32 + lane] = sb2;
-        }
-        for (int e = tid; e < NBC * NBC; e += 256) {
-            const int r = e >> 6, c = e & 63;
-            Ud[r][c] = (r < pw && c < pw && c >= r) ? U[(long)(p0 + r) * ld + p0 + c] : (r == c ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (wave < 2) {                            // wave 0: mu, wave 1: x
-            double* vec = wave == 0 ? h : xz;
-            double v = lane < pw ? vec[p0 + lane] - ((part[0][wave][lane] + part[1][wave][lane]) + (part[2][wave][lane] + part[3][wave][lane])) : 0.0;
-            for (int i = pw - 1; i >= 0; --i) {
-                const double xi = __shfl(v, i) / Ud[i][i];
-                if (lane == i) v = xi; else if (lane < i) v -= Ud[lane][i] * xi;
-            }
-            if (lane < pw) vec[p0 + lane] = v;
-        }
-        __syncthreads();
-    }
-    // scatter: zeros for inactive blocks
-    const int D = g.N * g.B;
-    double* W = g.W + (long)n * D;
-    for (int i = tid; i < D; i += 256) W[i] = 0.0;
     __syncthreads();
-    const int* act = g.act + (long)n * g.ldact;
-    for (int i = tid; i < na; i += 256) {
-        const double v = h[i] + xz[i];
-        if (i == na - 1) g.b[n] = v; else W[act[i]] = v;
+    // rows above the panel: 16 lanes per row (4 consecutive doubles each), 4 rows per wave-instruction, 16 rows per wave and trip
+    const int rl = lane >> 4, cl = (lane & 15) * 4;
+    const double v0 = vp[cl], v1 = vp[cl + 1], v2 = vp[cl + 2], v3 = vp[cl + 3];
+    const int rend = min(p0, r0 + BS_ROWS);
+    for (int rb = r0 + wave * 16; rb < rend; rb += 64) {
+        double acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rb + q * 4 + rl;
+            acc[q] = 0.0;
+            if (row < rend) {
+                const double* up = U + (long)row * ld + p0 + cl;
+                if (cl + 3 < pw) { const d2_t a = *reinterpret_cast<const d2_t*>(up), b = *reinterpret_cast<const d2_t*>(up + 2); acc[q] = (a[0] * v0 + a[1] * v1) + (b[0] * v2 + b[1] * v3); }
+                else { for (int c = 0; c < 4; ++c) if (cl + c < pw) acc[q] += up[c] * vp[cl + c]; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double a = acc[q];
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+            const int row = rb + q * 4 + rl;
+            if ((lane & 15) == 0 && row < rend) r[row] -= a;
+        }
     }
+}
+
+// scatter (after W has been zeroed): mu + x -- one vector, the solve of w + z -- for the active blocks, the bias last
+__global__ __launch_bounds__(256) void scatter_active_kernel(CholArgs g, long plane) {
+    const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int na = g.na[n];
+    if (i >= na) return;
+    const double val = g.hc[(long)n * g.ldc + plane + i];
+    if (i == na - 1) g.b[n] = val; else g.W[(long)n * g.N * g.B + g.act[(long)n * g.ldact + i]] = val;
 }
 
 }  // namespace
@@ -242,22 +229,24 @@ int pgl_k_chol_index(const PglCholState& s, hipStream_t st) {
     return PGL_OK;
 }
 
-// na_max: host-side upper bound of the active sizes (read back from s.na by the caller)
+// na_max: host-side upper bound of the active sizes (every neuron stops at its own na[n])
 int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     CholArgs g = mk(s);
     if (na_max <= 0) return PGL_OK;
     hipLaunchKernelGGL(gather_active_kernel, dim3((na_max + 63) / 64, (na_max + 63) / 64, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
+    // the products see na + 1 columns (the h column rides along): extents from nd = na_max + 1, per-neuron sizes as na[n] - (c0 - 1)
+    const int nd = na_max + 1;
     auto trailing = [&](int krow0, int K, int c0, int mfix) -> int {
         // C[c0.., c0..] -= P' P with P = rows [krow0, krow0+K) of Ac, columns from c0 (k-major panel)
         PglGemmArgs t{};
         const double* P = s.Ac + (long)krow0 * s.ldc + c0;
-        const int rem = na_max - c0;
+        const int rem = nd - c0;
         t.A = P; t.lda = s.ldc; t.strideA = s.strideC;
         t.B = P; t.ldb = s.ldc; t.strideB = s.strideC;
         t.C = s.Ac + (long)c0 * s.ldc + c0; t.ldc = s.ldc; t.strideC = s.strideC;
         t.N = rem; t.K = K; t.a_cols = rem + (rem & 1); t.b_cols = t.a_cols; t.nbatch = s.nb; t.nz_total = 0;
-        t.alpha = -1.0; t.beta = 1.0; t.batch_k = nullptr; t.batch_dim = s.na; t.dim_off = c0; t.W = nullptr; t.ldw = 0;
+        t.alpha = -1.0; t.beta = 1.0; t.batch_k = nullptr; t.batch_dim = s.na; t.dim_off = c0 - 1; t.W = nullptr; t.ldw = 0;
         // strip: mfix rows only -- and never rows past a neuron's own remainder (they would land in the padding or, beyond ldc, in the next
         // neuron's block)
         if (mfix > 0) { t.M = mfix; t.tri = 0; t.dim_mode = 3; return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st); }
@@ -266,13 +255,13 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     };
     auto panel_solve = [&](int q0) -> int {
         // rows [q0, q0+64), columns from q0+64:  A12 <- L^-1 A12  (in place: a tile reads its 64 x 256 block completely before storing it)
-        const int c0 = q0 + NBC, rem = na_max - c0;
+        const int c0 = q0 + NBC, rem = nd - c0;
         PglGemmArgs t{};
         t.A = s.Tinv; t.lda = NBC; t.strideA = (long)NBC * NBC; t.a_cols = NBC;
         t.B = s.Ac + (long)q0 * s.ldc + c0; t.ldb = s.ldc; t.strideB = s.strideC; t.b_cols = rem + (rem & 1);
         t.C = s.Ac + (long)q0 * s.ldc + c0; t.ldc = s.ldc; t.strideC = s.strideC;
         t.M = NBC; t.N = rem; t.K = NBC; t.nbatch = s.nb; t.alpha = 1.0; t.beta = 0.0; t.tri = 0;
-        t.batch_dim = s.na; t.dim_off = c0; t.dim_mode = 1;
+        t.batch_dim = s.na; t.dim_off = c0 - 1; t.dim_mode = 1;
         return pgl_launch_gemm(PGL_GEMM_PLAIN, t, st);
     };
     // super-panels of SP 64-row sub-panels: before sub-panel i is factored its 64-row strip takes the updates of sub-panels 0..i-1 (one
@@ -290,15 +279,26 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
             }
             hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, qi);
             PGL_CHECK_LAUNCH();
-            if (na_max - qi - NBC <= 0) { done = true; break; }
+            if (nd - qi - NBC <= 0) { done = true; break; }
             const int rc = panel_solve(qi);
             if (rc) return rc;
         }
-        if (done || na_max - q0 - SP * NBC <= 0) break;
+        if (done || nd - q0 - SP * NBC <= 0) break;
         const int rc = trailing(q0, SP * NBC, q0 + SP * NBC, 0);        // rank-256 update of everything right of / below the super-panel
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(solve_sample_kernel, dim3(s.nb), dim3(256), 0, st, g);
+    // U (mu + x) = w + z, panel by panel from the last; then the scatter
+    const long plane = (long)s.nb * s.ldc;
+    hipLaunchKernelGGL(backsolve_init_kernel, dim3((na_max + 255) / 256, s.nb), dim3(256), 0, st, g);
+    PGL_CHECK_LAUNCH();
+    for (int pi = (na_max + NBC - 1) / NBC - 1; pi >= 0; --pi) {
+        const int rows_above = pi * NBC;
+        const int nblk = rows_above > 0 ? (rows_above + BS_ROWS - 1) / BS_ROWS : 1;
+        hipLaunchKernelGGL(backsolve_panel_kernel, dim3(nblk, s.nb), dim3(256), 0, st, g, pi, plane);
+        PGL_CHECK_LAUNCH();
+    }
+    if (hipMemsetAsync(s.W, 0, (size_t)s.nb * s.N * s.B * sizeof(double), st) != hipSuccess) { pgl_set_error("memset failed"); return PGL_ERR_HIP; }
+    hipLaunchKernelGGL(scatter_active_kernel, dim3((na_max + 255) / 256, s.nb), dim3(256), 0, st, g, plane);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

@@ -398,10 +398,10 @@ class GibbsEngine(object):
         mp, planes = lib.pgl_i8_max_planes(), plan["planes"]
         Ts = plan["slice"] or T
         pb1, r1 = lib.pgl_i8_plane_bytes(self.D, Ts) // mp * planes, lib.pgl_i8_residue_bytes(self.D) // mp * planes
-        G, pas = plan["G"], (0 if plan["resident"] else pb1)
+        G, pas, T0 = plan["G"], (0 if plan["resident"] else pb1), 0
         if self._i8_scratch:
-            _, _, G0, PB, R, _, S0, PAs = self._i8_scratch
-            if G0 == G and S0 == plan["slice"] and PB.numel() >= G * pb1 and R.numel() >= G * r1 and (PAs.numel() if PAs is not None else 0) >= pas:
+            _, T0, G0, PB, R, _, S0, PAs = self._i8_scratch[:8]
+            if G0 == G and S0 == plan["slice"] and T0 >= T and PB.numel() >= G * pb1 and R.numel() >= G * r1 and (PAs.numel() if PAs is not None else 0) >= pas:
                 return
             if S0 != plan["slice"] and (S0 or plan["slice"]):
                 raise _lib.PglError("data sets with different time slicing of the integer Gram in one engine (add the largest first)")
@@ -410,10 +410,11 @@ class GibbsEngine(object):
             G = min(G, G0)
         self._i8_scratch = None
         torch.cuda.empty_cache()
-        self._i8_scratch = (G * (pb1 + r1) + pas, T, G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
+        self._i8_scratch = (G * (pb1 + r1) + pas, max(T, T0), G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
                             torch.empty(G * r1, dtype=torch.int8, device=self.dev),
                             self._z(3, G, self.D),          # per group: column maxima, sums of squares, scales of omega_g X
-                            plan["slice"], torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None)
+                            plan["slice"], torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None,
+                            self._z(-(-max(T, T0) // 256) * G * 2 * self.D))         # partial column statistics per 256-bin block (pgl_sweep_t.i8_part)
 
     @_on_device
     def drop_int8(self, i):
@@ -559,7 +560,7 @@ class GibbsEngine(object):
                         ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
                         ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
                         ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
-                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, int(nrun),
+                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, int(nrun),
                         int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
                         ctypes.pointer(self._times) if self.profile else None)
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
@@ -604,7 +605,7 @@ class GibbsEngine(object):
         statistics -> scales -> per time slice: residue planes -> int8 products mod p (added up in the residues) -> CRT"""
         D, Dp, ldj = self.D, self.Dp, self.ldj
         st = self._st()
-        _, _, G, PB, R, stat, S, PAs = self._i8_scratch
+        _, _, G, PB, R, stat, S, PAs = self._i8_scratch[:8]
         assert gz <= G
         npl = ds.planes
         call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)

@@ -102,6 +102,39 @@ def test_device_pg_ks_against_gamma_series(torch_dev, b, z):
     assert stats.ks_2samp(om, ref).pvalue > 1e-3
 
 
+@pytest.mark.parametrize("b", [13.7, 50.0, 170.0])
+@pytest.mark.parametrize("z", [0.0, 2.0, 20.0])
+def test_device_pg_series_branch_on_two_million_draws(torch_dev, b, z):
+    """the series branch of the device sampler (every b > 12, every fractional shape: 32 terms + a moment-matched gamma remainder) at
+    n = 2e6 per case: mean, variance and THIRD cumulant against the exact values of the defining series (each within 5 standard errors
+    of the sample statistic), and a two-sample Kolmogorov-Smirnov test against an independent sampler of the same series -- 2000 terms,
+    gamma variates from torch's generator on the GPU (n = 1e6).  tests/test_oracle_pg.py bounds analytically what the truncation changes
+    (nothing in cumulants 1-2, 4e-11 .. 1.4e-6 of the third); this is the empirical side."""
+    torch = torch_dev
+    from scipy import stats
+    from tests.test_oracle_pg import pg_cumulant
+    n = 2000000
+    om = _device_pg(b, z, n, 23, orc.stream_id(int(b), int(z) + 1))
+    assert np.all(om > 0) and np.all(np.isfinite(om))
+    k1, k2, k3 = (pg_cumulant(b, z, j) for j in (1, 2, 3))
+    xc = om - om.mean()
+    m2, m3, m4, m6 = (float(np.mean(xc ** j)) for j in (2, 3, 4, 6))
+    assert abs(om.mean() - k1) < 5 * np.sqrt(k2 / n)
+    assert abs(m2 - k2) < 5 * np.sqrt((m4 - m2 * m2) / n)
+    se3 = np.sqrt(max(m6 - m3 * m3 - 6 * m4 * m2 + 9 * m2 ** 3, 0.0) / n)
+    assert abs(m3 - k3) < 5 * se3, (m3, k3, se3)
+    # independent series sampler on the GPU, in chunks: w = sum_k g_k / d_k over 2000 terms + the (deterministic) mean of what is left
+    gen = torch.Generator(device="cuda:0").manual_seed(int(1000 * b + z))
+    K, nref, chunk = 2000, 1000000, 50000
+    c = z * z / (4 * np.pi ** 2)
+    dk = torch.tensor(2 * np.pi ** 2 * ((np.arange(1, K + 1) - 0.5) ** 2 + c), device="cuda:0")
+    tail = k1 - b * float((1.0 / dk).sum())
+    conc = torch.full((chunk, K), float(b), dtype=torch.float64, device="cuda:0")
+    ref = torch.cat([(torch._standard_gamma(conc, generator=gen) / dk).sum(1) + tail for _ in range(nref // chunk)]).cpu().numpy()
+    res = stats.ks_2samp(om[:nref], ref)
+    assert res.pvalue > 1e-3, (b, z, res)
+
+
 def test_device_pg_real_shapes_match_oracle(torch_dev):
     """real-valued shapes on a shared stream: the series branch consumes the stream identically on both sides; the remainder's moments are
     computed by different formulas (closed form on the device, term-by-term sums in the oracle), hence 1e-8 instead of 1e-12"""
