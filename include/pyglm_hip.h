@@ -262,9 +262,6 @@ typedef struct {
                                     * holds i8_group slices of pgl_i8_plane_bytes(D, i8_slice) */
     void* i8_PAs;                  /* planes of one slice of X, pgl_i8_plane_bytes(D, i8_slice): used for data sets with int8 = 1 and PA = NULL
                                     * (their X planes are converted per slice instead of kept) */
-    double* i8_part;               /* optional: [ceil(T / 256)][i8_group][2][D] for the longest data set.  With it the column statistics of a group's
-                                    * omega X are taken by the plane passes (partials per 256-bin block, folded in a fixed order; the pass that
-                                    * converts one group takes the next group's) instead of by a pass of their own; NULL: separate pass */
     int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
                                     * this GPU (bench.py scaling_proxy); the state of the others is left alone */
     /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */

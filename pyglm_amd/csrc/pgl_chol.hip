@@ -81,63 +81,97 @@ __global__ __launch_bounds__(256) void gather_active_kernel(CholArgs g) {
     if (i0 == 0 && j0 == 0 && threadIdx.x == 0) Ac[(long)na * g.ldc + na] = 0.0;
 }
 
-// factor the 64x64 diagonal block at q0: A11 = U11' U11, U11 written to the upper triangle in place
-__global__ __launch_bounds__(256) void potrf_diag_kernel(CholArgs g, int q0) {
-    const int n = blockIdx.x, tid = threadIdx.x;
+// factor the 64 x 64 diagonal block at q0: A11 = U11' U11 (U11 written to the upper triangle in place) and Tinv = the inverse of the lower
+// factor L = U11', k-major, for the row-panel solve U12 = L^-1 A12 on the MFMA contraction.
+// ONE WAVE per neuron, the block in registers: lane i holds row i of the lower triangle (64 doubles).  A step of the right-looking
+// factorisation reads what the other rows contribute with v_readlane (the row index is the loop counter of a fully unrolled loop, so
+// every register index is static): no LDS, no barrier.  The inverse is the forward substitution L X = I run the same way, row k
+// broadcast lane by lane as it becomes final.  (The first version kept the block in LDS with three workgroup barriers per column and
+// one thread per column of the inverse: 180 us per launch, 81 launches per batch at cfg3, 513 at configs[4].)
+template <int P>
+__device__ __forceinline__ double lane_bcast(double v) {      // value of lane P, in every lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), P), hi = __builtin_amdgcn_readlane(__double2hiint(v), P);
+    return __hiloint2double(hi, lo);
+}
+template <int P, int J>
+__device__ __forceinline__ void potrf_row_update(double (&a)[NBC], double lip) {
+    if constexpr (J < NBC) {
+        a[J] -= lip * lane_bcast<J>(a[P]);                    // A[i][J] -= L[i][P] L[J][P]   (entries above the diagonal: unused garbage)
+        potrf_row_update<P, J + 1>(a, lip);
+    }
+}
+template <int P>
+__device__ __forceinline__ void potrf_steps(double (&a)[NBC], int lane, int& bad) {
+    if constexpr (P < NBC) {
+        double d = lane_bcast<P>(a[P]);
+        if (!(d > 0.0)) { bad = 1; d = 1.0; }
+        const double r = sqrt(d), inv = 1.0 / r;
+        a[P] = lane == P ? r : a[P] * inv;                    // column P of L (rows below the diagonal scaled; rows above: unused)
+        potrf_row_update<P, P + 1>(a, a[P]);
+        potrf_steps<P + 1>(a, lane, bad);
+    }
+}
+template <int K, int J>
+__device__ __forceinline__ void inv_row_update(double (&x)[NBC], double lik, bool below) {
+    if constexpr (J <= K) {
+        // (the broadcast is taken by ALL lanes and the update applied by a select: a v_readlane under a divergent branch reads a lane
+        // the compiler considers inactive -- undefined in its model, and wrong in practice)
+        const double xk = lane_bcast<K>(x[J]);
+        x[J] = below ? x[J] - lik * xk : x[J];                // X[i][J] -= L[i][K] X[K][J]   for the rows i > K
+        inv_row_update<K, J + 1>(x, lik, below);
+    }
+}
+template <int K>
+__device__ __forceinline__ void inv_steps(const double (&a)[NBC], double (&x)[NBC], int lane) {
+    if constexpr (K < NBC) {
+        // row K of X is final once scaled by 1 / L[K][K]; rows below it take its contribution
+        const double rk = 1.0 / lane_bcast<K>(a[K]);
+#pragma unroll
+        for (int j = 0; j <= K; ++j) x[j] = lane == K ? x[j] * rk : x[j];
+        inv_row_update<K, 0>(x, a[K], lane > K);
+        inv_steps<K + 1>(a, x, lane);
+    }
+}
+template <int K>
+__device__ __forceinline__ void hcol_steps(const double (&a)[NBC], double& v, int lane) {
+    if constexpr (K < NBC) {
+        const double wk = lane_bcast<K>(v) / lane_bcast<K>(a[K]);
+        if (lane == K) v = wk; else if (lane > K) v -= a[K] * wk;
+        hcol_steps<K + 1>(a, v, lane);
+    }
+}
+
+__global__ __launch_bounds__(64) void potrf_diag_kernel(CholArgs g, int q0) {
+    const int n = blockIdx.x, lane = threadIdx.x;
     const int na = g.na[n];
     if (q0 >= na) return;
     const int nb = min(NBC, na - q0);
-    __shared__ double A[NBC][NBC + 1];
-    __shared__ int s_bad;
     double* Ag = g.Ac + (long)n * g.strideC + (long)q0 * g.ldc + q0;
-    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; A[i][j] = Ag[(long)(i <= j ? i : j) * g.ldc + (i <= j ? j : i)]; }
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-    // right-looking lower Cholesky on the symmetric block (L = U11'), column by column
-    for (int p = 0; p < nb; ++p) {
-        if (tid == 0) { double d = A[p][p]; if (!(d > 0.0)) { s_bad = 1; d = 1.0; } A[p][p] = sqrt(d); }
-        __syncthreads();
-        const double dinv = 1.0 / A[p][p];
-        for (int i = p + 1 + tid; i < nb; i += 256) A[i][p] *= dinv;
-        __syncthreads();
-        const int rem = nb - p - 1;
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int i = p + 1 + e / rem, j = p + 1 + e % rem;
-            if (j <= i) A[i][j] -= A[i][p] * A[j][p];
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (i <= j) Ag[(long)i * g.ldc + j] = A[j][i]; }
-    if (tid == 0 && s_bad) atomicOr(&g.status[n], 4);
+    // row `lane` of the lower triangle = column `lane` of the stored upper one; the identity beyond a short last block
+    double a[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) a[j] = (lane < nb && j <= lane) ? Ag[(long)j * g.ldc + lane] : (j == lane ? 1.0 : 0.0);
+    int bad = 0;
+    potrf_steps<0>(a, lane, bad);
+#pragma unroll
+    for (int j = 0; j < NBC; ++j)
+        if (lane < nb && j <= lane) Ag[(long)j * g.ldc + lane] = a[j];          // U11[j][lane] = L[lane][j]
+    if (lane == 0 && bad) atomicOr(&g.status[n], 4);
     // the neuron's last block, not a full one: column na (the h column) lies inside it, where no panel solve reaches -- L w = h here
-    // (one wave: unknown j per lane, a step is a broadcast and one multiply-add)
-    if (q0 + nb == na && nb < NBC && tid < 64) {
+    if (q0 + nb == na && nb < NBC) {
         double* hcol = g.Ac + (long)n * g.strideC + (long)q0 * g.ldc + na;
-        double v = tid < nb ? hcol[(long)tid * g.ldc] : 0.0;
-        for (int j = 0; j < nb; ++j) {
-            const double wj = __shfl(v, j) / A[j][j];
-            if (tid == j) v = wj; else if (tid > j && tid < nb) v -= A[tid][j] * wj;
-        }
-        if (tid < nb) hcol[(long)tid * g.ldc] = v;
+        double v = lane < nb ? hcol[(long)lane * g.ldc] : 0.0;
+        hcol_steps<0>(a, v, lane);
+        if (lane < nb) hcol[(long)lane * g.ldc] = v;
     }
-    // inverse of the lower factor, one column per thread (forward substitution on e_j); the row-panel solve
-    // U12 = U11^-T A12 = L^-1 A12 then runs on the MFMA contraction with Tinv[k][m] = (L^-1)[m][k] as its k-major operand
-    __shared__ double Li[NBC][NBC + 1];
-    if (tid < NBC) {
-        const int j = tid;
-        for (int i = 0; i < NBC; ++i) {
-            double sacc = (i == j) ? 1.0 : 0.0;
-            if (i < nb && j < nb) {
-                for (int k = j; k < i; ++k) sacc -= A[i][k] * Li[k][j];
-                Li[i][j] = (i >= j) ? sacc / A[i][i] : 0.0;
-            } else {
-                Li[i][j] = 0.0;
-            }
-        }
-    }
-    __syncthreads();
+    // X = L^-1 (lower): row `lane` in registers, starting from the identity
+    double x[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) x[j] = j == lane ? 1.0 : 0.0;
+    inv_steps<0>(a, x, lane);
     double* Tn = g.Tinv + (long)n * NBC * NBC;
-    for (int e = tid; e < NBC * NBC; e += 256) { const int k = e / NBC, m = e % NBC; Tn[e] = Li[m][k]; }
+#pragma unroll
+    for (int k = 0; k < NBC; ++k) Tn[k * NBC + lane] = (lane >= k && lane < nb && k < nb) ? x[k] : 0.0;     // Tinv[k][m] = (L^-1)[m][k]
 }
 
 // r = w + z: w from column na of the factored block, z the standard normals (U (mu + x) = w + z gives the draw in one solve)
@@ -277,7 +311,7 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
                 const int rc = trailing(q0, i * NBC, qi, NBC);          // strip: rows of sub-panel i, columns from its diagonal block
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(256), 0, st, g, qi);
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(64), 0, st, g, qi);
             PGL_CHECK_LAUNCH();
             if (nd - qi - NBC <= 0) { done = true; break; }
             const int rc = panel_solve(qi);

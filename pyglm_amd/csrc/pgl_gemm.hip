@@ -109,7 +109,11 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     // they only feed output rows / columns that are never stored.
     d2_t ra[C::A_LD], rb[C::B_LD];                   // (ext-vector type: HIP's double2 struct ends up in scratch here)
     double rw = 0.0;
-    const double asign = CINIT ? g.alpha : 1.0;     // CINIT: alpha = +-1 is folded into the A operand on its way to LDS
+    // CINIT: alpha = +-1 is folded into the A operand on its way to LDS -- as a flip of the sign bits (integer XOR: an f64 multiply
+    // by -1 gives the same bits but goes through the pipe the MFMAs use, and every MFMA -> f64 VALU -> MFMA switch costs)
+    const unsigned long long aflip = (CINIT && g.alpha < 0.0) ? 0x8000000000000000ull : 0ull;
+    typedef unsigned long long u2_t __attribute__((ext_vector_type(2)));
+    auto signed_a = [&](d2_t v) { return __builtin_bit_cast(d2_t, __builtin_bit_cast(u2_t, v) ^ u2_t{aflip, aflip}); };
     unsigned oa_[C::A_LD], ob_[C::B_LD], ow_ = 0;                  // per-thread byte offsets inside a K tile (constant)
     const char* ka_ = reinterpret_cast<const char*>(Ab);            // wave-uniform bases of the K tile to load next
     const char* kb_ = reinterpret_cast<const char*>(Bb);
@@ -149,7 +153,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
         for (int i = 0; i < C::A_LD; ++i) {
             const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-            if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[i] * asign;
+            if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = signed_a(ra[i]);
             else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[i];
         }
 #pragma unroll
@@ -230,7 +234,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 double* Bs = As + C::A_ELEMS;
                 if (q < C::A_LD) {
                     const int p = tid + q * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-                    if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[q] * asign;
+                    if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = signed_a(ra[q]);
                     else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[q];
                 } else {
                     const int i = q - C::A_LD;

@@ -151,9 +151,6 @@ struct PlaneArgs {
     const double* scale;                  // [G][D] fixed-point scale of column d of neuron g (i8_scales_kernel)
     int8_t* P;                            // [G][np] planes of Dq * Kp bytes, blocked [Dq / 16][Kp / 64][16][64]
     int T, D, Dq; long Kp; int np;
-    // column statistics of omega_s X for GS further weight columns (the NEXT group's), taken from the x values this pass holds anyway
-    // (i8_planes_t_kernel only): partial (max |v|, sum v^2) per 256-bin time block, part[(tblk0 + block) * GS + s][2][D]
-    const double* OmS; long ldos; int GS; double* part; int tblk0;
 };
 
 // A workgroup converts 256 time bins x 16 columns (one row block, four K tiles) of X, staged ONCE in LDS, for all G neurons of the group.
@@ -248,8 +245,6 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
 template <int PT_T>
 __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
     __shared__ double oms[CS_G][PT_T + 2];
-    __shared__ double omss[CS_G][PT_T + 2];                // the weight columns whose statistics ride along
-    __shared__ double red[2][PT_T / 64][PT_D][CS_G];
     const int t0 = blockIdx.x * PT_T, d0 = blockIdx.y * PT_D;
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, r = l >> 2, tb = 64 * w + 16 * (l & 3);
@@ -271,47 +266,11 @@ __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
             for (int k = 0; k < 16; ++k) x[k] = (live && d < a.D && t + k < a.T) ? src[k] : 0.0;
         }
     }
-    if (a.Om || a.GS > 0) {
+    if (a.Om) {
         const int t = t0 + tid;
-        if (a.Om) {
-            const double* src = a.Om + (long)t * a.ldo;
-            for (int g = 0; g < G; ++g) oms[g][tid] = t < a.T ? src[g] : 0.0;
-        }
-        if (a.GS > 0) {
-            const double* src = a.OmS + (long)t * a.ldos;
-            for (int g = 0; g < a.GS; ++g) omss[g][tid] = t < a.T ? src[g] : 0.0;
-        }
+        const double* src = a.Om + (long)t * a.ldo;
+        for (int g = 0; g < G; ++g) oms[g][tid] = t < a.T ? src[g] : 0.0;
         __syncthreads();
-    }
-    if (a.GS > 0) {
-        // statistics of the NEXT group's omega_s X over this workgroup's 256 bins x 16 rows: per thread over its 16 bins, over the four
-        // lanes of a row (fixed tree), over the four waves (in order): every step in a fixed order, so the sums -- and with them the
-        // scales and every bit of J -- do not depend on launch timing, on the grouping or on the time slicing (blocks are 256 bins
-        // from t = 0).  v is the same product the conversion rounds.  A NaN is dropped by fmax and caught through the sum of squares.
-        for (int g = 0; g < a.GS; ++g) {
-            double m = 0.0, q = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double v = x[k] * omss[g][tb + k];
-                m = fmax(m, fabs(v));
-                q = fma(v, v, q);
-            }
-            m = fmax(m, __shfl_xor(m, 1)); q += __shfl_xor(q, 1);
-            m = fmax(m, __shfl_xor(m, 2)); q += __shfl_xor(q, 2);
-            if ((l & 3) == 0) { red[0][w][r][g] = m; red[1][w][r][g] = q; }
-        }
-        __syncthreads();
-        if (tid < PT_D * CS_G) {
-            const int rr = tid % PT_D, g = tid / PT_D;
-            if (g < a.GS && d0 + rr < a.D) {
-                double mm = 0.0, qq = 0.0;
-#pragma unroll
-                for (int ww = 0; ww < PT_T / 64; ++ww) { mm = fmax(mm, red[0][ww][rr][g]); qq += red[1][ww][rr][g]; }
-                double* out = a.part + ((long)(a.tblk0 + blockIdx.x) * a.GS + g) * 2 * a.D + d0 + rr;
-                out[0] = mm;
-                out[a.D] = qq;
-            }
-        }
     }
     if (!live) return;
     const long nkt = a.Kp / 64;
@@ -354,21 +313,6 @@ __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
             }
         }
     }
-}
-
-// amax[s][c] = max over the time blocks, ss[s][c] = sum over them IN ORDER of the partials the plane passes left (i8_planes_t_kernel)
-__global__ __launch_bounds__(256) void i8_stats_fold_kernel(const double* __restrict__ part, int nblk, int GS, int D, double* __restrict__ amax,
-                                                            double* __restrict__ ss) {
-    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (c >= D) return;
-    double mm = 0.0, qq = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const double* p = part + ((long)b * GS + g) * 2 * D + c;
-        mm = fmax(mm, p[0]);
-        qq += p[D];
-    }
-    amax[(long)g * D + c] = mm;
-    ss[(long)g * D + c] = qq;
 }
 
 // ------------------------------------------------------------------ int8 Gram of the planes, reduced mod p
@@ -915,7 +859,7 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
                     int nplanes, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
-    PlaneArgs a{X, ldx, transposed, Om, ldo, scale, P, T, D, Dq, Kp, nplanes, nullptr, 0, 0, nullptr, 0};
+    PlaneArgs a{X, ldx, transposed, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
     // 512 time bins per workgroup: 8 KiB contiguous per plane and row block.  Measured on one box, ms per group of 8 at cfg3, with the
     // non-temporal stores: 256 bins 13.6, 512 bins 12.5, 1024 bins 12.4 (with ordinary stores the three were within 2 %).
     const bool aligned = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
@@ -926,32 +870,6 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
         hipLaunchKernelGGL(i8_planes_t_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
     else
         hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
-    PGL_CHECK_LAUNCH();
-    return PGL_OK;
-}
-
-// The conversion pass of a group (G >= 0 weight columns at Om; G = 0: no planes are written) that ALSO takes the column statistics of
-// GS <= 8 further weight columns at OmS -- the next group's -- from the x values it holds in registers: partials per 256-bin block
-// [t0 / 256 + block] into `part`, folded by pgl_k_i8_stats_fold.  Xt must be the transposed design matrix at bin t0 (16-byte aligned,
-// t0 a multiple of 256 so that the blocks of all slices tile the data set from t = 0).
-int pgl_k_i8_planes_stats(const double* Xt, long ldx, const double* Om, long ldo, const double* scale, int8_t* P, int T, int D, int G, int nplanes,
-                          const double* OmS, long ldos, int GS, double* part, int t0, hipStream_t st) {
-    const int Dq = pgl_k_i8_padded_rows(D);
-    const long Kp = pgl_i8_kp(T);
-    if (G > CS_G || GS > CS_G || G < 0 || GS < 0 || (G == 0 && GS == 0)) { pgl_set_error("i8 planes+stats: %d / %d weight columns (max %d each)", G, GS, CS_G); return PGL_ERR_ARG; }
-    if (ldx % 2 != 0 || reinterpret_cast<uintptr_t>(Xt) % 16 != 0 || t0 % 256 != 0) { pgl_set_error("i8 planes+stats: unaligned slice (t0 = %d)", t0); return PGL_ERR_ARG; }
-    PlaneArgs a{Xt, ldx, 1, G > 0 ? Om : nullptr, ldo, scale, P, T, D, Dq, Kp, G > 0 ? nplanes : 0, OmS, ldos, GS, part, t0 / 256};
-    // (a statistics-only pass covers the bins, not the padded plane length)
-    const long span = G > 0 ? Kp : ((long)T + 255) / 256 * 256;
-    if (G == 0) a.Kp = span;
-    hipLaunchKernelGGL(i8_planes_t_kernel<256>, dim3((unsigned)((span + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
-    PGL_CHECK_LAUNCH();
-    return PGL_OK;
-}
-
-int pgl_k_i8_stats_fold(const double* part, int T, int GS, int D, double* amax, double* ss, hipStream_t st) {
-    const int nblk = (T + 255) / 256;
-    hipLaunchKernelGGL(i8_stats_fold_kernel, dim3((D + 255) / 256, GS), dim3(256), 0, st, part, nblk, GS, D, amax, ss);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

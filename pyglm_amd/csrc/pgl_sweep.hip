@@ -237,7 +237,6 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         c0 = s->c0_dense;
     }
 
-    bool stats_ready = false;          // integer Gram: the scales of the group about to run were already taken by the previous plane pass
     for (int s0 = 0; s0 < nrun; s0 += nb) {
         const int nbb = nb < nrun - s0 ? nb : nrun - s0;
         // ---- likelihood Gram of neurons [s0, s0 + nbb)  (regression.py:251-252)
@@ -258,48 +257,21 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 double* amax = s->i8_stat;
                 double* ss = s->i8_stat + (long)G * D;
                 double* sB = s->i8_stat + 2L * G * D;
-                // time slices (BASELINE configs[4]: one neuron's planes are 86 GB): the integer Gram is a sum over time, so the slices'
-                // products add up in the residues; a data set without resident X planes converts those per slice too
-                const int slice = s->i8_slice > 0 && s->i8_slice < d.T ? s->i8_slice : d.T;
-                // column statistics of omega_g X (the scales come from them).  With the partials buffer they are taken by the plane
-                // passes themselves (pgl_k_i8_planes_stats: 256-bin blocks, folded in order): the pass that converts group g also takes
-                // the statistics of group g + 1 from the x values it holds -- one pass over X per group instead of two; only the very
-                // first group of a sweep needs a statistics-only pass.  (Several data sets interleave their groups: then every group
-                // takes its own statistics-only pass, same kernel, same numbers.)  Without the buffer: the separate colstats kernel.
-                static const int stats_mode = [] { const char* e = getenv("PGL_I8_STATS"); return !e ? 2 : e[0] == 'l' ? 0 : e[0] == 'p' ? 1 : 2; }();   // A/B: legacy / pass / fused
-                const bool blocks = stats_mode > 0 && s->i8_part != nullptr && (slice == d.T || slice % 256 == 0) && (reinterpret_cast<uintptr_t>(d.Xt) % 16 == 0) && d.Tp % 2 == 0;
-                const bool fuse = blocks && s->ndatasets == 1 && stats_mode == 2;
                 for (int g0 = 0; g0 < nbb; g0 += G) {
                     const int gz = G < nbb - g0 ? G : nbb - g0;
                     const double* om = d.OK + s0 + g0;
-                    // the group after this one (possibly the first of the next batch)
-                    const int nx = s0 + g0 + gz;
-                    int gzn = 0;
-                    if (fuse && nx < nrun) {
-                        const int bend = (nx / nb + 1) * nb < nrun ? (nx / nb + 1) * nb : nrun;
-                        gzn = G < bend - nx ? G : bend - nx;
-                    }
-                    const double* omn = d.OK + nx;
                     auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
-                    if (!blocks) {
-                        RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
-                        RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
-                    } else if (!stats_ready) {
-                        for (int t0 = 0; t0 < d.T; t0 += slice) {
-                            const int ts = slice < d.T - t0 ? slice : d.T - t0;
-                            RC(pgl_k_i8_planes_stats(d.Xt + t0, d.Tp, nullptr, 0, nullptr, nullptr, ts, (int)D, 0, np, om + (long)t0 * 2 * ldn, 2 * ldn, gz, s->i8_part, t0, st));
-                        }
-                        RC(pgl_k_i8_stats_fold(s->i8_part, d.T, gz, (int)D, amax, ss, st));
-                        RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
-                    }
+                    RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
+                    RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
                     clk.toc(m);
+                    // time slices (BASELINE configs[4]: one neuron's planes are 86 GB): the integer Gram is a sum over time, so the
+                    // slices' products add up in the residues; a data set without resident X planes converts those per slice too
+                    const int slice = s->i8_slice > 0 && s->i8_slice < d.T ? s->i8_slice : d.T;
                     for (int t0 = 0; t0 < d.T; t0 += slice) {
                         const int ts = slice < d.T - t0 ? slice : d.T - t0;
                         m = clk.tic(ST_PLANES, (double)np * (gz + (d.PA ? 0 : 1)) * ts * D);
                         if (!d.PA) RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, nullptr, 0, d.sA, static_cast<int8_t*>(s->i8_PAs), ts, (int)D, 1, np, st));
-                        if (blocks) RC(pgl_k_i8_planes_stats(d.Xt + t0, d.Tp, om + (long)t0 * 2 * ldn, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), ts, (int)D, gz, np,
-                                                             gzn ? omn + (long)t0 * 2 * ldn : nullptr, 2 * ldn, gzn, s->i8_part, t0, st));
-                        else RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, om + (long)t0 * 2 * ldn, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), ts, (int)D, gz, np, st));   // (coalesced rows of Xt)
+                        RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, om + (long)t0 * 2 * ldn, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), ts, (int)D, gz, np, st));   // (coalesced rows of Xt)
                         clk.toc(m);
                         m = clk.tic(ST_I8, (double)gz * ts * D * (D + 1));
                         if (d.PA) RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), pgl_k_i8_kp(d.T), t0 / 64, static_cast<const int8_t*>(s->i8_PB),
@@ -311,14 +283,6 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     m = clk.tic(ST_CRT, (double)np * gz * D * (D + 1) / 2);
                     RC(pgl_k_i8_crt(static_cast<const int8_t*>(s->i8_R), d.sA, sB, s->Jbuf + (long)g0 * strideJ, ldj, strideJ, (int)D, gz, np, i > 0, st));
                     clk.toc(m);
-                    stats_ready = false;
-                    if (gzn > 0) {          // the partials of the next group are complete: its scales replace this group's (the CRT above was their last reader)
-                        m = clk.tic(ST_STATS, 0.0);
-                        RC(pgl_k_i8_stats_fold(s->i8_part, d.T, gzn, (int)D, amax, ss, st));
-                        RC(pgl_k_i8_scales(amax, ss, (long)gzn * D, d.T, np, sB, st));
-                        clk.toc(m);
-                        stats_ready = true;
-                    }
                 }
             }
         }

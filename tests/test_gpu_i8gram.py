@@ -357,8 +357,7 @@ def test_sweep_with_integer_gram_equals_fp64_sweep_and_oracle(N, B, T, batch):
 def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
     """BASELINE configs[4] cannot hold a neuron's planes at once: the integer Gram then runs in time slices whose products add up in the
     residues (pgl_i8_gram_slice), with X's planes either resident or converted per slice.  The arithmetic is exact, so J and the whole
-    sweep must come out bit for bit as without slices -- including a last slice that is shorter and not a multiple of 64 (slices are
-    multiples of 256 bins: the column statistics are taken per 256-bin block by the plane passes themselves)."""
+    sweep must come out bit for bit as without slices -- including a last slice that is shorter and not a multiple of 64."""
     from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
     rng = np.random.default_rng(11)
     N, B, T = 70, 5, 2300
@@ -372,7 +371,7 @@ def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
     rho = np.full((N, N), 0.5)
     perm, u, z = make_draws(5, 0, range(N), N, D)
     res = []
-    for slc in (None, "768", "1024"):
+    for slc in (None, "640", "1024"):
         if slc is None:
             monkeypatch.delenv("PGL_I8_SLICE", raising=False)
             monkeypatch.delenv("PGL_I8_RESIDENT", raising=False)
