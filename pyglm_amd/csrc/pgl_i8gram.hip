@@ -11,17 +11,21 @@
 // |a_i||b_j| at K = 13 (a column whose norm is one outlier element is held at 2^49..2^50 by the element bound at every K) -- for ANY
 // dynamic range: the precision is pinned to the column norms, not to the column maxima.  Roundings of REPEATED values are not independent
 // (a design matrix of filtered spikes takes few distinct values per column): measured on the bench's data the error is ~5x that model,
-// still several times below the fp64 kernel's own (DESIGN.md section 8c, tests/test_gpu_i8gram.py).
+// still several times below the fp64 kernel's own (DESIGN.md section 8, tests/test_gpu_i8gram.py).
 //
 //   i8_colstats_kernel max_t |v| and sum_t v^2 per column of X (once per data set) and of omega_g X (per neuron and sweep), deterministic
 //   i8_scales_kernel   the scale of every column from those statistics
-//   i8_planes_kernel   fp64 (t-major) -> K residue planes in BLOCKED layout [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once
-//                      per data set), PB[g] for omega_g X (per neuron, per sweep); one pass over X per group of neurons; residues by four
-//                      fp64 operations each (no integer division)
-//   i8_gram_kernel     R[g][q] = (PA[q] PB[g][q]') mod p_q on lower 256 x 256 tiles (v_mfma_i32_16x16x64_i8; 8 waves = 2 x 4, wave tile
-//                      128 x 64; K tiles DMA-staged into 4 LDS stages, one contiguous KiB per request, 16-byte chunks XOR-swizzled:
-//                      conflict-free ds_read_b128); persistent workgroups, per-XCD work lists in a clustered tile order (L2 sharing)
-//   i8_crt_kernel      K residues -> mixed-radix digits (Garner) -> fp64 by Horner -> unscaled into the lower triangle of J
+//   i8_planes_t_kernel fp64 (the TRANSPOSED design matrix: a column's bins are contiguous) -> K residue planes in BLOCKED layout
+//                      [row / 16][K tile of 64 bins][row % 16][64 B]: PA for X (once per data set, or per time slice where they cannot stay
+//                      resident), PB[g] for omega_g X (per neuron, per sweep); a lane keeps its 16 bins in registers for all neurons of a
+//                      group; a residue is three fp64 instructions (no integer division); i8_planes_kernel: the same from the t-major X
+//   i8_gram_kernel     R[g][q] = (PA[q] PB[g][q]') mod p_q on lower 320 x 320 tiles (v_mfma_i32_16x16x64_i8; 4 waves = 2 x 2, ONE wave per
+//                      SIMD, wave tile 160 x 160 = 100 accumulators of 16 x 16 split over AGPRs and VGPRs by inline-asm register classes;
+//                      K tiles DMA-staged into 3 LDS stages of 40 KiB, one contiguous KiB per request, 16-byte chunks XOR-swizzled:
+//                      conflict-free ds_read_b128); persistent workgroups, per-XCD work lists in a clustered tile order (L2 sharing);
+//                      int32 sums re-reduced every 128 000 bins; time slices of a data set add up in R (accumulate).  The 256 x 256-tile
+//                      kernel of round 1 (two waves per SIMD) is kept behind PGL_I8_TILE=256
+//   i8_crt_kernel      K residues -> mixed-radix digits (Garner) -> fp64 by Horner -> unscaled (exponent arithmetic) into the lower triangle of J
 #include "pgl_common.h"
 #include <cmath>
 #include <cstdlib>

@@ -266,7 +266,9 @@ class NonlinearAutoregressiveModel(object):
         a, W, b = self._local_state()
         versions = tuple(r._hyp_version for r in regs)
         cache = getattr(self, "_hyper_cache", None)
-        if cache is not None and cache[0] == versions:
+        # the cached terms are those of a network push (or of the last sweep) and are only trusted while nobody outside holds one of the
+        # live hyper-parameter arrays (regression._handed_out): such a holder may edit in place at any time, as users of the reference do
+        if cache is not None and cache[0] == versions and not any(r._handed_out for r in regs):
             rho, Jw, hw, Jb, hb, c0 = cache[1]          # pushed by resample_network and untouched since
         else:
             hyp = [r._hyper() for r in regs]            # internal read: does not mark the terms stale (the public properties do)
@@ -409,9 +411,9 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
             return
         sigma, mu, rho = net.sigma_W, net.mu_W, net.rho
         for n, reg in enumerate(self.regressions):
-            reg.S_w = sigma[n]
-            reg.mu_w = mu[n]
-            reg.rho = rho[n]
+            reg._set("_S_w", np.array(sigma[n]))      # (copies: the regression owns its hyper-parameters, as after the reference's setters)
+            reg._set("_mu_w", np.array(mu[n]))
+            reg._set("_rho", np.array(rho[n]))
         self._cache_pushed_hypers(sigma, mu, rho)
 
     def _cache_block_hypers(self, mu_off, S_off, mu_self, S_self, rho):

@@ -38,7 +38,7 @@ class _SparseScalarRegressionBase(object):
         # (the legacy generator fills an array by the same successive draws), the factor is formed once per DISTINCT covariance instead of
         # a million times at N = 1024, and the per-row product is the same 1-D np.dot: same seed -> the same initial chain as the
         # reference, bit for bit (fixture G13, tests/test_host_logic.py).
-        self.a = npr.rand(N) < self.rho
+        self.a = npr.rand(N) < self._rho
         self.W = np.zeros((N, B))
         Z = npr.standard_normal((N, B))
         factors = {}
@@ -52,7 +52,7 @@ class _SparseScalarRegressionBase(object):
             x = np.dot(Z[n], M)
             x += mu_all[n]
             self.W[n] = x
-        self.b = npr.multivariate_normal(self.mu_b, self.S_b)
+        self.b = npr.multivariate_normal(self._mu_b, self._S_b)
         self._engine_cache = None
         self._lik_engine_cache = None
 
@@ -61,10 +61,16 @@ class _SparseScalarRegressionBase(object):
     # properties: a getter hands out the live array, and the reference's users edit those in place (`reg.rho[m] = 0.9`) -- after such a
     # read the terms are recomputed from the arrays, as the reference does every sweep (:266).  Internal code reads `_hyper()`.
     _hyp_version = 0
+    _handed_out = frozenset()       # hyper-parameter arrays somebody outside may still hold: their cached terms are never trusted
 
-    def _set(self, name, value):
+    def _set(self, name, value, given=None):
         setattr(self, name, value)
         self._hyp_version = self._hyp_version + 1
+        # an array the caller passed in and that was stored as it is (no copy) stays editable in the caller's hands
+        if isinstance(given, np.ndarray) and isinstance(value, np.ndarray) and np.shares_memory(value, given):
+            self._handed_out = self._handed_out | {name}
+        else:
+            self._handed_out = self._handed_out - {name}
 
     def _get_rows(self, name):
         v = getattr(self, name)
@@ -74,24 +80,29 @@ class _SparseScalarRegressionBase(object):
         return v
 
     def _touch(self, name, rows=False):
+        # a getter hands out the LIVE array: whoever keeps it can edit it at any later time (`rho = reg.rho; ...; rho[m] = 0.9` after
+        # further sweeps), which no version counter sees.  From here on the terms of this regression are recomputed from the arrays every
+        # sweep, as the reference does (:266), until the array is replaced by an assignment or a network push.
         self._hyp_version = self._hyp_version + 1
+        self._handed_out = self._handed_out | {name}
         return self._get_rows(name) if rows else getattr(self, name)
 
     def _hyper(self):
         """(rho, S_w, mu_w, S_b, mu_b) without marking the cached terms stale"""
         return self._rho, self._get_rows("_S_w"), self._get_rows("_mu_w"), self._S_b, self._mu_b
 
-    rho = property(lambda self: self._touch("_rho"), lambda self, v: self._set("_rho", expand_scalar(v, (self.N,))))
-    mu_w = property(lambda self: self._touch("_mu_w", True), lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B))))
-    mu_b = property(lambda self: self._touch("_mu_b"), lambda self, v: self._set("_mu_b", expand_scalar(v, (1,))))
-    S_w = property(lambda self: self._touch("_S_w", True), lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B))))
+    rho = property(lambda self: self._touch("_rho"), lambda self, v: self._set("_rho", expand_scalar(v, (self.N,)), v))
+    mu_w = property(lambda self: self._touch("_mu_w", True), lambda self, v: self._set("_mu_w", expand_scalar(v, (self.N, self.B)), v))
+    mu_b = property(lambda self: self._touch("_mu_b"), lambda self, v: self._set("_mu_b", expand_scalar(v, (1,)), v))
+    S_w = property(lambda self: self._touch("_S_w", True), lambda self, v: self._set("_S_w", expand_cov(v, (self.N, self.B, self.B)), v))
 
     def _push_block_prior(self, mu_off, S_off, mu_self, S_self, n, rho_row):
         """the hyper-parameter push of models.py:233-236 for a prior with one shared weight block and (optionally) one for the
         self-connection n: same values as assigning the expanded (N, B) / (N, B, B) arrays, which are only built if somebody reads them"""
         self._mu_w = _BlockRows(mu_off, mu_self, n)
         self._S_w = _BlockRows(S_off, S_self, n)
-        self._set("_rho", expand_scalar(rho_row, (self.N,)))
+        self._handed_out = self._handed_out - {"_mu_w", "_S_w"}
+        self._set("_rho", np.array(expand_scalar(rho_row, (self.N,))))          # (a copy: the network keeps its own array)
 
     @property
     def S_b(self):
@@ -105,14 +116,15 @@ class _SparseScalarRegressionBase(object):
     @property
     def natural_params(self):
         """(:138-151)"""
-        J_w = np.linalg.inv(self.S_w)
-        h_w = np.einsum("nij,nj->ni", J_w, self.mu_w)
-        J_b = np.linalg.inv(self.S_b)
-        return J_w, h_w, J_b, J_b.dot(self.mu_b)
+        rho, S_w, mu_w, S_b, mu_b = self._hyper()
+        J_w = np.linalg.inv(S_w)
+        h_w = np.einsum("nij,nj->ni", J_w, mu_w)
+        J_b = np.linalg.inv(S_b)
+        return J_w, h_w, J_b, J_b.dot(mu_b)
 
     @property
     def deterministic_sparsity(self):
-        return bool(np.all((self.rho < 1e-6) | (self.rho > 1 - 1e-6)))
+        return bool(np.all((self._rho < 1e-6) | (self._rho > 1 - 1e-6)))
 
     def _flatten_X(self, X):
         X = np.asarray(X)
@@ -169,10 +181,11 @@ class _SparseScalarRegressionBase(object):
         from .engine import make_draws, prior_terms
         eng = self._engine(datas)
         seed = int(npr.randint(2 ** 31)) if seed is None else seed
-        Jw, hw, Jb, hb, c0 = prior_terms(self.S_w[None], self.mu_w[None], self.S_b.reshape(1), self.mu_b.reshape(1))
+        rho_, S_w_, mu_w_, S_b_, mu_b_ = self._hyper()
+        Jw, hw, Jb, hb, c0 = prior_terms(S_w_[None], mu_w_[None], S_b_.reshape(1), mu_b_.reshape(1))
         perm, u, z = make_draws(seed, sweep, [0], self.N, self.N * self.B)
         self._before_sweep(eng)
-        a, W, b, _ = eng.sweep(self.a[None], self.W[None], self.b, self.rho[None], Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep)
+        a, W, b, _ = eng.sweep(self.a[None], self.W[None], self.b, rho_[None], Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep)
         self.a, self.W, self.b = a[0], W[0], b.reshape(1)
         self._after_sweep(eng, seed, sweep)
 

@@ -119,12 +119,18 @@ def test_cfg2_full_sweeps_invariants():
         assert np.abs(resid).max() <= 1e-8 * np.abs(hp[m]).max()
 
 
-def test_dense_maximum_size_cholesky_path():
-    """a dense-prior regression (rho = 1, no flips, BASELINE.json configs[4] style) at D = 16384: the blocked Cholesky, the
-    triangular solves and the rank-64 MFMA updates on a 16385-dimensional system; checked through J mu = h."""
+@pytest.mark.parametrize("N", [2048, 4096])
+def test_dense_maximum_size_cholesky_path(N):
+    """a dense-prior regression (rho = 1: regression.py:153-155, 274-275 -- no flips, every block on) at D = 16 384 and at BASELINE.json
+    configs[4]'s own D = 32 768 (N = 4096, B = 8; T kept short, the weight draw does not depend on it): the blocked Cholesky with the
+    forward solve riding along as column na, the panel-wise backward solve and the rank-256 MFMA updates on a 32 769-dimensional
+    system -- the largest the code will ever factor; checked through J mu = h and (x - mu)' J (x - mu) = z'z."""
+    import gc
     import torch
     from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
-    N, B, T = 2048, 8, 4000
+    gc.collect()
+    torch.cuda.empty_cache()
+    B, T = 8, 4000
     basis, Y, rng = _problem(N, B, T, L=50, seed=2)
     eng = GibbsEngine(N, B, 0, 2, batch=2)
     eng.add_data(Y, basis=basis)

@@ -254,6 +254,22 @@ def test_in_place_hyper_edits_reach_the_next_sweep():
         r.rho[1] = 1.0
     m.resample_regressions()
     np.testing.assert_array_equal(m.adjacency, np.tile(np.array([False, True, False, False]), (N, 1)))
+    # a handle taken BEFORE earlier sweeps and edited afterwards (no getter call in between: nothing a version counter could see)
+    m3 = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
+    m3.add_data(Y)
+    held = [r.rho for r in m3.regressions]
+    m3.resample_regressions()
+    m3.resample_regressions()
+    for h in held:
+        h[:] = 0.0
+        h[2] = 1.0
+    m3.resample_regressions()
+    np.testing.assert_array_equal(m3.adjacency, np.tile(np.array([False, False, True, False]), (N, 1)))
+    # ... and after a network push the arrays are new objects nobody holds: the cache is trusted again
+    m3.resample_network()
+    assert not any(r._handed_out for r in m3.regressions)
+    m3.resample_regressions()
+    assert m3._hyper_cache[0] == tuple(r._hyp_version for r in m3.regressions)
     m2 = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=1, engine_factory=OracleEngine)
     m2.add_data(Y)
     m2.resample_regressions()
