@@ -260,8 +260,8 @@ typedef struct {
                                     * * planes / 15 suffices), [3][i8_group][D] */
     int i8_slice;                  /* time bins per slice of the integer Gram (a multiple of 64; 0 = the whole data set at once): i8_PB then
                                     * holds i8_group slices of pgl_i8_plane_bytes(D, i8_slice) */
-    void* i8_PAs;                  /* planes of one slice of X, pgl_i8_plane_bytes(D, i8_slice): used for data sets with int8 = 1 and PA = NULL
-                                    * (their X planes are converted per slice instead of kept) */
+    void* i8_PAs;                  /* planes of one slice of X, pgl_i8_plane_bytes(D, i8_slice or T): used for data sets with int8 = 1 and PA = NULL
+                                    * (their X planes are converted per slice -- per group where there is one slice -- instead of kept) */
     int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
                                     * this GPU (bench.py scaling_proxy); the state of the others is left alone */
     /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */

@@ -154,7 +154,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
         PGL_CHECK_ARG(d.T > 0 && d.Tp >= d.T && d.Tp % 16 == 0 && d.X && d.Xt && d.Y && d.Psi && d.OK && d.llpart);
-        PGL_CHECK_ARG(!d.int8 || (d.sA && (d.PA || (s->i8_PAs && s->i8_slice > 0)) && (d.planes > 0 || s->planes > 0)));
+        PGL_CHECK_ARG(!d.int8 || (d.sA && (d.PA || s->i8_PAs) && (d.planes > 0 || s->planes > 0)));      // (no resident X planes: converted per slice -- or once per group for the whole data set -- into i8_PAs)
         any_i8 = any_i8 || d.int8;
     }
     PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= 8 && s->obs != 2));

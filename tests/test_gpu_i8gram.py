@@ -371,16 +371,21 @@ def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
     rho = np.full((N, N), 0.5)
     perm, u, z = make_draws(5, 0, range(N), N, D)
     res = []
-    for slc in (None, "640", "1024"):
+    for slc in (None, "0", "640", "1024"):          # "0": one slice, but X's planes (resident = "0") converted per group instead of kept
         if slc is None:
             monkeypatch.delenv("PGL_I8_SLICE", raising=False)
             monkeypatch.delenv("PGL_I8_RESIDENT", raising=False)
         else:
-            monkeypatch.setenv("PGL_I8_SLICE", slc)
+            if slc == "0":
+                monkeypatch.delenv("PGL_I8_SLICE", raising=False)
+                slc = None if resident == "1" else "0"
+            else:
+                monkeypatch.setenv("PGL_I8_SLICE", slc)
             monkeypatch.setenv("PGL_I8_RESIDENT", resident)
         eng = GibbsEngine(N, B, gram="int8", batch=N)
         ds = eng.add_data(Y, X=X)
         assert ds.int8 and (eng._i8_scratch[6] == (int(slc) if slc else 0)) and ((ds.PA is None) == (slc is not None and resident == "0"))
+        assert (eng._i8_scratch[7] is not None) == (ds.PA is None)
         out = eng.sweep(a, W, b, rho, *hyp, perm, u, z, seed=5, sweep=0)
         res.append((eng.Jbuf[:, :D + 2, :D + 2].cpu().numpy().copy(), out))
         del eng
