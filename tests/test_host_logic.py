@@ -436,3 +436,33 @@ def test_initial_state_is_the_references_draw_at_every_size(golden):
         np.testing.assert_array_equal(r.a, golden["I_%s_a" % tag])
         np.testing.assert_array_equal(r.W, golden["I_%s_W" % tag])
         np.testing.assert_array_equal(np.asarray(r.b), golden["I_%s_b" % tag])
+
+
+def test_shard_override_sweeps_its_rows_only():
+    """`shard=(n0, n1)` (bench.py --neurons: k neurons of one rank's shard of a config too large for the GPUs at hand) sweeps exactly those
+    regressions -- with the same random inputs as a full model, so their new rows equal the full model's -- and leaves every other row of
+    (A, W, b) as it was; nothing is exchanged."""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(11)
+    N, B, T = 6, 2, 250
+    Y = (np.random.rand(T, N) < 0.2).astype(float)
+    kw = dict(B=B, regression_kwargs=dict(S_w=2.0, mu_b=-1.0), seed=5, engine_factory=OracleEngine)
+    np.random.seed(3)
+    full = SparseBernoulliGLM(N, **kw)
+    np.random.seed(3)
+    part = SparseBernoulliGLM(N, shard=(2, 5), **kw)
+    assert (part.n0, part.n1) == (2, 5)
+    for m in (full, part):
+        m.add_data(Y)
+    A0, W0, b0 = part.adjacency.copy(), part.weights.copy(), part.biases.copy()
+    np.testing.assert_array_equal(A0, full.adjacency)
+    full.resample_regressions()
+    part.resample_regressions()
+    np.testing.assert_array_equal(part.adjacency[2:5], full.adjacency[2:5])
+    np.testing.assert_allclose(part.weights[2:5], full.weights[2:5], rtol=0, atol=0)
+    for lo, hi in ((0, 2), (5, N)):
+        np.testing.assert_array_equal(part.adjacency[lo:hi], A0[lo:hi])
+        np.testing.assert_array_equal(part.weights[lo:hi], W0[lo:hi])
+        np.testing.assert_array_equal(part.biases[lo:hi], b0[lo:hi])
+    assert np.isfinite(part.log_likelihood())
