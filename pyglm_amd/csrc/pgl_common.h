@@ -70,6 +70,7 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
 // the update pipeline (pgl_update.hip): 256 x 128 tiles, DMA-staged, persistent; pgl_launch_gemm routes products marked `pipe` to it
 bool pgl_update_supported(const PglGemmArgs& a);
 int pgl_launch_update(const PglGemmArgs& a, hipStream_t st);
+int pgl_launch_update_rows(const PglGemmArgs& a, int row0, int nrows, hipStream_t st);
 // 8 zeroed per-XCD work counters for one persistent launch on stream st (a ring of slots owned by the library; pgl_gemm.hip)
 int* pgl_sched_slot(hipStream_t st);
 

@@ -816,7 +816,19 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
-        case PGL_GEMM_TRI1: PGL_CHECK_ARG(a.M == a.N); return launch<2, 2, 1, false>(a, st);
+        case PGL_GEMM_TRI1: {
+            PGL_CHECK_ARG(a.M == a.N);
+            // a lower triangle whose last few rows would open a tile row of their own (a tableau: D + 2 rows, 41 of 861 tiles for the bias and
+            // potential rows at cfg3): those rows through the skinny kernel of pgl_update.hip (same bits), the tiles on the rest
+            const int extra = a.M % 128;
+            if (a.pipe && a.tri == 1 && a.batch_dim == nullptr && a.M > 128 && extra >= 1 && extra <= 16 && pgl_update_supported(a)) {
+                if (int rc = pgl_launch_update_rows(a, a.M - extra, extra, st)) return rc;
+                PglGemmArgs b = a;
+                b.M = b.N = a.M - extra;
+                return launch<2, 2, 1, false>(b, st);
+            }
+            return launch<2, 2, 1, false>(a, st);
+        }
     }
     pgl_set_error("unknown gemm kind %d", (int)kind);
     return PGL_ERR_ARG;

@@ -489,3 +489,16 @@ int pgl_launch_update(const PglGemmArgs& a, hipStream_t st) {
     if (!pgl_update_supported(a)) { pgl_set_error("update pipeline: unsupported product"); return PGL_ERR_ARG; }
     return a.tri == 2 ? launch_update<true>(a, st) : launch_update<false>(a, st);
 }
+
+// rows [row0, row0 + nrows) (nrows <= 16) of C (+)= alpha A'B over all N columns, through the skinny kernel: what the last few rows of a
+// lower-triangular update cost when they are not given a tile row of their own (a tableau has D + 2 rows: two rows that would be 41 tiles
+// of 861 at cfg3).  Same MFMA, same K order as the tiles: same bits.
+int pgl_launch_update_rows(const PglGemmArgs& a, int row0, int nrows, hipStream_t st) {
+    if (!pgl_update_supported(a) || nrows < 1 || nrows > 16 || row0 < 0 || a.batch_dim != nullptr) { pgl_set_error("update rows: unsupported product"); return PGL_ERR_ARG; }
+    UpdArgs u{};
+    u.g = a;
+    u.cinit = a.beta == 1.0 ? 1 : 0;
+    hipLaunchKernelGGL(update_rows_kernel, dim3((unsigned)((a.N + 127) / 128), (unsigned)a.nbatch), dim3(256), 0, st, u, row0, nrows);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
