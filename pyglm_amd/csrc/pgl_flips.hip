@@ -20,11 +20,14 @@
 // (the non-pivot formula is the same for forward and reverse sweeps; derivation in DESIGN.md).  The rank-k update
 // runs on the fp64 MFMA kernel (pgl_gemm.hip, lower-triangular tiles only).
 #include "pgl_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int KMAX = 512;   // max pivots (scalar rows) per tableau update: a chunk of the initial sweep (rank-512 passes over the tableau)
-constexpr int KWIN = 320;   // max scalar rows of the blocks of one proposal window (its sub-tableau lives in an L2-resident global scratch)
+constexpr int KWIN = 240;   // max scalar rows of the blocks of one proposal window (its sub-tableau lives in an L2-resident global scratch).
+                            // Measured at cfg3 (256 neurons, proposals + window updates, ms): 120: 229, 160: 205, 200: 194, 240: 190, 320: 205, 400: 238,
+                            // 500: 295 -- a flip costs the window's sub-tableau squared, a window one pass over the trailing tableau
 
 struct FlipArgs {
     double* M; long ldj; long strideM;           // tableau per neuron
@@ -588,7 +591,8 @@ size_t pgl_k_flip_lds_decide(int B, int R) {
 
 
 int pgl_k_flip_window_blocks(int B) {
-    int r = KWIN / B;                                   // blocks per window: at most KMAX pivots ...
+    static const int kwin = [] { const char* e = getenv("PGL_FLIP_WINDOW"); const int v = e ? atoi(e) : KWIN; return v >= 16 && v <= KMAX - 2 ? v : KWIN; }();   // A/B switch
+    int r = kwin / B;                                   // blocks per window: at most KMAX pivots ...
     while (r > 1 && pgl_k_flip_lds_decide(B, r) > 150 * 1024) --r;   // ... and the LDS scratch of decide_kernel must fit
     return r < 1 ? 0 : r;
 }
