@@ -13,6 +13,7 @@
 // spreads over as many workgroups as it has rows / 256, and U streams through once.  (One workgroup per neuron doing all of it took
 // 34 ms per batch at cfg3 and over a second per batch at the 32 769-dim systems of configs[4].)
 #include "pgl_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -300,8 +301,8 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     };
     // super-panels of SP 64-row sub-panels: before sub-panel i is factored its 64-row strip takes the updates of sub-panels 0..i-1 (one
     // rank-64i strip update), and the trailing matrix is updated ONCE per super-panel with rank 64 SP.  The trailing passes stream the
-    // whole remaining matrix (HBM-bound at rank 128): SP = 4 halves them again.
-    constexpr int SP = 4;
+    // whole remaining matrix (HBM-bound at rank 128): SP = 4 halves them again, SP = 6 is the measured optimum.
+    static const int SP = [] { const char* e = getenv("PGL_CHOL_SP"); const int v = e ? atoi(e) : 6; return v >= 1 && v <= 8 ? v : 6; }();      // A/B switch (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274)
     bool done = false;
     for (int q0 = 0; q0 < na_max && !done; q0 += SP * NBC) {
         for (int i = 0; i < SP; ++i) {
