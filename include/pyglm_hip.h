@@ -262,6 +262,10 @@ typedef struct {
                                     * holds i8_group slices of pgl_i8_plane_bytes(D, i8_slice) */
     void* i8_PAs;                  /* planes of one slice of X, pgl_i8_plane_bytes(D, i8_slice or T): used for data sets with int8 = 1 and PA = NULL
                                     * (their X planes are converted per slice -- per group where there is one slice -- instead of kept) */
+    void* i8_Rx;                   /* optional: 3 * i8_group * Dq^2 bytes.  With it (and full groups of 8) the product kernel cuts the items of the LAST
+                                    * residue plane into four K quarters, which evens out its final rounds (13 x 136 items per XCD of 32 CUs at
+                                    * BASELINE configs[2]: 55.25 rounds -> 51 + 17/4); the quarters' residues are added by the CRT.  NULL: no split.
+                                    * Exact integer arithmetic either way: the same J to the last bit */
     int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
                                     * this GPU (bench.py scaling_proxy); the state of the others is left alone */
     /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */

@@ -189,7 +189,7 @@ int pgl_i8_planes_t(const double* Xt, long ldt, const double* Om, long ldo, cons
 int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, int nplanes, void* st) {
     PGL_CHECK_ARG(planes_x && planes_wx && residues && T > 0 && D > 0 && G > 0);
     PGL_CHECK_PLANES(nplanes, T);
-    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), 0, 0, static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), T, D, G,
+    return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), 0, 0, static_cast<const int8_t*>(planes_wx), static_cast<int8_t*>(residues), nullptr, T, D, G,
                          nplanes, 0, ST(st));
 }
 int pgl_i8_gram_slice(const void* planes_x, int T_x, int t0, const void* planes_wx, void* residues, int T_slice, int T_total, int D, int G, int nplanes,
@@ -198,13 +198,13 @@ int pgl_i8_gram_slice(const void* planes_x, int T_x, int t0, const void* planes_
     PGL_CHECK_ARG(T_x == 0 || t0 + T_slice <= T_x);
     PGL_CHECK_PLANES(nplanes, T_total);
     return pgl_k_i8_gram(static_cast<const int8_t*>(planes_x), T_x > 0 ? pgl_k_i8_kp(T_x) : 0, T_x > 0 ? t0 / 64 : 0, static_cast<const int8_t*>(planes_wx),
-                         static_cast<int8_t*>(residues), T_slice, D, G, nplanes, accumulate, ST(st));
+                         static_cast<int8_t*>(residues), nullptr, T_slice, D, G, nplanes, accumulate, ST(st));
 }
 int pgl_i8_crt(const void* residues, const double* scale_x, const double* scale_wx, double* J, long ldj, long strideJ, int T, int D, int G,
                int nplanes, int accumulate, void* st) {
     PGL_CHECK_ARG(residues && scale_x && scale_wx && J && T > 0 && D > 0 && G > 0 && ldj >= D);
     PGL_CHECK_PLANES(nplanes, T);
-    return pgl_k_i8_crt(static_cast<const int8_t*>(residues), scale_x, scale_wx, J, ldj, strideJ, D, G, nplanes, accumulate, ST(st));
+    return pgl_k_i8_crt(static_cast<const int8_t*>(residues), nullptr, scale_x, scale_wx, J, ldj, strideJ, D, G, nplanes, accumulate, ST(st));
 }
 
 static PglFlipState to_state(const pgl_flip_t* s) {

@@ -109,9 +109,9 @@ double pgl_k_i8_norm_limit(int, int);
 int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
 int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
 int pgl_k_i8_planes(const double*, long, int transposed, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);
-int pgl_k_i8_gram(const int8_t*, long, int, const int8_t*, int8_t*, int, int, int, int, int, hipStream_t);
+int pgl_k_i8_gram(const int8_t*, long, int, const int8_t*, int8_t*, int8_t*, int, int, int, int, int, hipStream_t);
 long pgl_k_i8_kp(int);
-int pgl_k_i8_crt(const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
+int pgl_k_i8_crt(const int8_t*, const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
 int pgl_k_flip_apply(const PglFlipState&, int, int, int, hipStream_t);
 int pgl_k_flip_permute(const PglFlipState&, const double*, long, long, hipStream_t);
 int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
 // ------------------------------------------------------------------ int8 Gram of the planes, reduced mod p
 constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
 constexpr int STAGE_BYTES = (TM + TN) * BKB;
-constexpr int GRAM_LDS = NST * STAGE_BYTES + 16;             // + the work ticket
+constexpr int GRAM_LDS = NST * STAGE_BYTES + 32;             // + the work ticket (five ints)
 constexpr int KCH = 2000;                                    // K tiles between re-reductions: 128 + 128000 * 128 * 128 < 2^31
 constexpr int CH = 32;                               // clustered tile order: super-blocks of SB x SB tiles; work-list chunk per XCD
 
@@ -338,6 +338,8 @@ struct GramArgs {
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
     long KpA; int ka0;                    // the X planes may be longer than this slice of the omega X planes: their bytes per row, first K tile
     int accum;                            // 320-tile kernel: add to the residues already in R (a later time slice of the same product)
+    int8_t* Rx;                           // 320-tile kernel, split of the LAST plane into K quarters: quarters 1..3 of neuron g's residues
+                                          // go to Rx[g][quarter - 1][Dq][Dq] (i8_crt adds the four); NULL: no split
 };
 
 __device__ __forceinline__ int isqrt_tri_i(int t) {
@@ -531,8 +533,9 @@ __device__ __forceinline__ void big_rows(v4i (&acc)[10][10], v4i (&FA)[5], v4i (
     }
 }
 
+// kpart < 0: the whole K range of this pass; 0..3: that quarter of it (split items of the last plane, see i8_gram_kernel)
 template <int BNST>
-__device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds) {
+__device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds, const int kpart = -1) {
     const int m0 = tm * BT, n0 = tn * BT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -556,12 +559,22 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
         const double x = (double)v;
         return (int)fma(-pq, rint(x * ipq), x);
     };
-    int8_t* R = g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
+    int8_t* R = kpart > 0 ? g.Rx + ((long)gz * 3 + (kpart - 1)) * g.Dq * g.Dq : g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
     // long data sets: the host launches one pass per chunk of KCH K tiles (the int32 sums cannot overflow within one); a pass adds its
     // residues to the previous passes' through the output bytes.  (A chunk loop in here makes hipcc spill the 400 accumulators.)
     {
-        const int kc = g.kt0;
-        const int nk = min(nkt - kc, KCH);
+        int kc = g.kt0;
+        int nk = min(nkt - kc, KCH);
+        if (kpart >= 0) {                                  // a quarter of the pass (quarters tile it: the last may be short)
+            const int quarter = (nk + 3) >> 2, kend = kc + nk;
+            kc += kpart * quarter;
+            nk = min(quarter, kend - kc);
+            if (nk <= 0) {                                 // (only for passes of fewer than 4 K tiles: an empty quarter contributes zero)
+                if (g.kt0 == 0 && !g.accum)
+                    for (int e = threadIdx.x; e < BT * BT; e += 256) R[(long)(m0 + e / BT) * g.Dq + n0 + e % BT] = 0;
+                return;
+            }
+        }
         const char* sb[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
@@ -668,7 +681,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
                         *dst8 = (int8_t)(v & 0xff);          // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
                     }
         };
-        if (kc == 0 && !g.accum) store(std::false_type{});
+        if (g.kt0 == 0 && !g.accum) store(std::false_type{});
         else store(std::true_type{});
     }
 }
@@ -687,9 +700,16 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
     int* ticket = reinterpret_cast<int*>(lds + (BIG ? 0 : NST * STAGE_BYTES));      // (320 tiles: aliases stage 0, which is idle between items)
     const int ntm = g.Dq / (BIG ? BT : TM);
     const int ntiles = ntm * (ntm + 1) / 2;
-    const int per_neuron = ntiles * g.np;
-    const int total = per_neuron * g.G;
     const bool by_neuron = g.by_neuron != 0;
+    // Balance of the last rounds (by-neuron lists, 320 tiles): an XCD's list is np x ntiles equal items for 32 CUs -- at cfg3 13 x 136 = 55.25
+    // rounds, and the quarter round at the end leaves 24 of 32 CUs idle for a whole item (1.4 % of the launch).  The LAST plane's items are
+    // therefore cut into four K quarters each (their residues land in four slots that i8_crt adds up: modular sums are exact in any
+    // order), taken 32 tiles x one quarter at a time so that co-running items still share their strips: 12 x 136 = 51 x 32 full items and
+    // 4 x 136 = 17 x 32 quarter items -- no partial round at cfg3, and never more than a quarter item of imbalance anywhere.
+    const bool split = BIG && by_neuron && g.Rx != nullptr;
+    const int nfull = split ? ntiles * (g.np - 1) : ntiles * g.np;
+    const int per_neuron = nfull + (split ? 4 * ntiles : 0);
+    const int total = per_neuron * g.G;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
@@ -707,9 +727,21 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
                 }
             }
             if (w >= 0) {
-                int tm, tn;
-                clustered_tile(w % ntiles, ntm, tm, tn, g.sb);
-                ticket[1] = w / ntiles; ticket[2] = tm; ticket[3] = tn;
+                int tm, tn, pair, kpart = -1, tile;
+                if (!split) { pair = w / ntiles; tile = w % ntiles; }
+                else {
+                    const int y = w / per_neuron, it = w % per_neuron;
+                    if (it < nfull) { pair = y * g.np + it / ntiles; tile = it % ntiles; }
+                    else {                                 // groups of 32 tiles (the last may be smaller), quarter-major inside a group
+                        const int r = it - nfull, grp = r / 128, within = r - grp * 128;
+                        const int tg = min(32, ntiles - grp * 32);
+                        kpart = within / tg;
+                        tile = grp * 32 + within % tg;
+                        pair = y * g.np + g.np - 1;
+                    }
+                }
+                clustered_tile(tile, ntm, tm, tn, g.sb);
+                ticket[1] = pair; ticket[2] = tm; ticket[3] = tn; ticket[4] = kpart;
             }
             ticket[0] = w;
         }
@@ -718,8 +750,9 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
         const int pair = __builtin_amdgcn_readfirstlane(ticket[1]);
         const int tm = __builtin_amdgcn_readfirstlane(ticket[2]), tn = __builtin_amdgcn_readfirstlane(ticket[3]);
         if constexpr (BIG) {
+            const int kpart = __builtin_amdgcn_readfirstlane(ticket[4]);
             __syncthreads();                               // the ticket lives in stage 0: everybody has read it before the first request lands there
-            i8_gram_item_big<BNST>(g, pair / g.np, pair % g.np, tm, tn, lds);
+            i8_gram_item_big<BNST>(g, pair / g.np, pair % g.np, tm, tn, lds, kpart);
         } else i8_gram_item(g, pair / g.np, pair % g.np, tm, tn, lds);
     }
 }
@@ -730,6 +763,7 @@ struct CrtArgs {
     const double* sA; const double* sB;   // scales: [D], [G][D]
     double* J; long ldj; long strideJ;    // [G] slots
     int D, Dq, G, accumulate, np;
+    const int8_t* Rx;                     // [G][3][Dq][Dq]: the other three K quarters of the last plane's residues (or NULL)
 };
 
 // 1 / x for a scale: a power of two (exponent arithmetic: no division), 1 for an empty column, NaN for a non-finite one
@@ -749,6 +783,12 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
     int w[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) w[q] = q < a.np ? *reinterpret_cast<const int*>(R + (long)q * a.Dq * a.Dq) : 0;
+    int wx[3] = {0, 0, 0};
+    if (a.Rx) {
+        const int8_t* Rx = a.Rx + (long)gz * 3 * a.Dq * a.Dq + (long)i * a.Dq + j0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wx[k] = *reinterpret_cast<const int*>(Rx + (long)k * a.Dq * a.Dq);
+    }
     const double ra = recip_scale(a.sA[i]);
     double out[4];
 #pragma unroll
@@ -756,6 +796,12 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
         int v[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q) v[q] = (int)(int8_t)((unsigned)w[q] >> (8 * e));
+        // the last plane came in four K quarters: any representative of the sum will do (it only enters the last digit's reduction)
+        if (a.Rx) {
+            const int x = (int)(int8_t)((unsigned)wx[0] >> (8 * e)) + (int)(int8_t)((unsigned)wx[1] >> (8 * e)) + (int)(int8_t)((unsigned)wx[2] >> (8 * e));
+#pragma unroll
+            for (int q = 1; q < NP; ++q) if (q == a.np - 1) v[q] += x;
+        }
         // Garner: mixed-radix digits with symmetric representatives, S = v0 + v1 p0 + v2 p0 p1 + ...;  digit q =
         // (r_q - sum_{k<q} v_k (p_0..p_{k-1} mod p_q)) (p_0..p_{q-1})^-1 mod p_q: the sum is accumulated unreduced (14 terms of at most
         // 128 * 128), so a digit costs q multiply-adds and ONE reduction instead of q reductions
@@ -880,7 +926,7 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
 
 // One time slice of the product: PB (and R's geometry) belong to the slice of T bins; the X planes start at K tile ka0 of rows that are KpA
 // bytes long (KpA = 0: they are a slice of their own, same geometry as PB).  accumulate: add to the residues of the earlier slices.
-int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t* R, int T, int D, int G, int nplanes, int accumulate, hipStream_t st) {
+int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t* R, int8_t* Rx, int T, int D, int G, int nplanes, int accumulate, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     const bool big = pgl_i8_tile() == BT;
@@ -906,7 +952,9 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
         static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();   // A/B switch: "chunk"
         // super-blocks of 6 x 6 tiles (measured on one box, ms per launch: 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
         static const bool idle_off = [] { const char* e = getenv("PGL_I8_IDLE"); return e && e[0] == '0'; }();                  // A/B switch
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, idle_off ? 0 : 1, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0};
+        static const bool split_off = [] { const char* e = getenv("PGL_I8_SPLIT"); return e && e[0] == '0'; }();               // A/B switch
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, idle_off ? 0 : 1, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0,
+                   (big && !split_off && nplanes >= 2) ? Rx : nullptr};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         if (big && big_stages == 4) hipLaunchKernelGGL((i8_gram_kernel<true, 4>), dim3(grid), dim3(256), 4 * BSTAGE, st, g);
         else if (big) hipLaunchKernelGGL((i8_gram_kernel<true, 3>), dim3(grid), dim3(256), 3 * BSTAGE, st, g);
@@ -916,11 +964,16 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
     return PGL_OK;
 }
 
-int pgl_k_i8_crt(const int8_t* R, const double* sA, const double* sB, double* J, long ldj, long strideJ, int D, int G, int nplanes, int accumulate,
-                 hipStream_t st) {
+// Rx: the three extra residue slots per neuron of a product that ran with the last plane split (pgl_k_i8_gram with the same Rx, G == 8
+// and the 320-tile kernel); NULL otherwise
+int pgl_k_i8_crt(const int8_t* R, const int8_t* Rx, const double* sA, const double* sB, double* J, long ldj, long strideJ, int D, int G, int nplanes,
+                 int accumulate, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     if (G <= 0) return PGL_OK;
-    CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes};
+    static const bool split_off = [] { const char* e = getenv("PGL_I8_SPLIT"); return e && e[0] == '0'; }();
+    static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();
+    const bool split = Rx != nullptr && !split_off && !map_chunks && G == 8 && nplanes >= 2 && pgl_i8_tile() == BT;       // = the condition in i8_gram_kernel
+    CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes, split ? Rx : nullptr};
     hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 1023) / 1024, D, G), dim3(256), 0, st, c);
     PGL_CHECK_LAUNCH();
     return PGL_OK;

@@ -275,13 +275,13 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                         clk.toc(m);
                         m = clk.tic(ST_I8, (double)gz * ts * D * (D + 1));
                         if (d.PA) RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), pgl_k_i8_kp(d.T), t0 / 64, static_cast<const int8_t*>(s->i8_PB),
-                                                   static_cast<int8_t*>(s->i8_R), ts, (int)D, gz, np, t0 > 0, st));
-                        else RC(pgl_k_i8_gram(static_cast<const int8_t*>(s->i8_PAs), 0, 0, static_cast<const int8_t*>(s->i8_PB), static_cast<int8_t*>(s->i8_R), ts,
-                                              (int)D, gz, np, t0 > 0, st));
+                                                   static_cast<int8_t*>(s->i8_R), static_cast<int8_t*>(s->i8_Rx), ts, (int)D, gz, np, t0 > 0, st));
+                        else RC(pgl_k_i8_gram(static_cast<const int8_t*>(s->i8_PAs), 0, 0, static_cast<const int8_t*>(s->i8_PB), static_cast<int8_t*>(s->i8_R),
+                                              static_cast<int8_t*>(s->i8_Rx), ts, (int)D, gz, np, t0 > 0, st));
                         clk.toc(m);
                     }
                     m = clk.tic(ST_CRT, (double)np * gz * D * (D + 1) / 2);
-                    RC(pgl_k_i8_crt(static_cast<const int8_t*>(s->i8_R), d.sA, sB, s->Jbuf + (long)g0 * strideJ, ldj, strideJ, (int)D, gz, np, i > 0, st));
+                    RC(pgl_k_i8_crt(static_cast<const int8_t*>(s->i8_R), static_cast<const int8_t*>(s->i8_Rx), d.sA, sB, s->Jbuf + (long)g0 * strideJ, ldj, strideJ, (int)D, gz, np, i > 0, st));
                     clk.toc(m);
                 }
             }

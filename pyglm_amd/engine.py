@@ -369,7 +369,7 @@ class GibbsEngine(object):
             for G in (8, 4, 2, 1):
                 if G > gmax:
                     continue
-                fixed = (pa_full if resident else 0) + G * r1
+                fixed = (pa_full if resident else 0) + G * r1 + (3 * G * lib.pgl_i8_padded_rows(self.D) ** 2 if G == 8 else 0)
                 S = (budget - fixed) // (per_bin * (G + (0 if resident else 1)))
                 cands.append((resident, G, int(S)))
         if forced:
@@ -413,7 +413,9 @@ class GibbsEngine(object):
         self._i8_scratch = (G * (pb1 + r1) + pas, max(T, T0), G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
                             torch.empty(G * r1, dtype=torch.int8, device=self.dev),
                             self._z(3, G, self.D),          # per group: column maxima, sums of squares, scales of omega_g X
-                            plan["slice"], torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None)
+                            plan["slice"], torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None,
+                            # the three extra residue slots per neuron of the K-quarter split of the last plane (full groups of 8 only)
+                            torch.empty(3 * G * lib.pgl_i8_padded_rows(self.D) ** 2, dtype=torch.int8, device=self.dev) if G == 8 else None)
 
     @_on_device
     def drop_int8(self, i):
@@ -559,7 +561,7 @@ class GibbsEngine(object):
                         ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
                         ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
                         ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
-                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, int(nrun),
+                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, int(nrun),
                         int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
                         ctypes.pointer(self._times) if self.profile else None)
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
