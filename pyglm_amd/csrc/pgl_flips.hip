@@ -25,9 +25,10 @@
 namespace {
 
 constexpr int KMAX = 512;   // max pivots (scalar rows) per tableau update: a chunk of the initial sweep (rank-512 passes over the tableau)
-constexpr int KWIN = 240;   // max scalar rows of the blocks of one proposal window (its sub-tableau lives in an L2-resident global scratch).
-                            // Measured at cfg3 (256 neurons, proposals + window updates, ms): 120: 229, 160: 205, 200: 194, 240: 190, 320: 205, 400: 238,
-                            // 500: 295 -- a flip costs the window's sub-tableau squared, a window one pass over the trailing tableau
+constexpr int KWIN = 320;   // max scalar rows of the blocks of one proposal window (its sub-tableau lives in an L2-resident global scratch).
+                            // A flip costs the window's sub-tableau squared, a window one pass over the trailing tableau; measured at cfg3 (256
+                            // neurons, proposals + window updates, ms per batch; PGL_FLIP_WINDOW): with ~13 % of the blocks flipping 240: 110,
+                            // 320: 98, 400: 93, 480: 96; with 30 %: 320: 149, 400: 154; with 50 %: 240: 190, 320: 205 -- the chain flips 7-35 %
 
 struct FlipArgs {
     double* M; long ldj; long strideM;           // tableau per neuron
@@ -73,13 +74,16 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
 
     const double* M = g.M + (long)n * g.strideM;
     const int* perm = g.perm + (long)n * N;
+    // the window's sub-tableau is symmetric: only its lower triangle (i >= j) is kept and updated -- half the read-modify-writes per flip
     for (int e = tid; e < nl * nl; e += nthr) {
         const int i = e / nl, j = e % nl;
+        if (j > i) continue;
         const int gi = (i < nl - 1) ? (g.permuted ? k0 * B + i : perm[k0 + i / B] * B + i % B) : D + 1;
         const int gj = (j < nl - 1) ? (g.permuted ? k0 * B + j : perm[k0 + j / B] * B + j % B) : D + 1;
         L[i * ldl + j] = tab_get(M, g.ldj, gi, gj);
     }
     __syncthreads();
+    auto Ls = [&](int i, int j) { return i >= j ? L[i * ldl + j] : L[j * ldl + i]; };
 
     const int hcol = nl - 1;
     for (int k = 0; k < nblk; ++k) {
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             }
             double quad = 0.0;
             for (int i = 0; i < B; ++i) {        // y = Lc^-1 v ;  quad = y'y = v' Q^-1 v
-                double s = L[(p0 + i) * ldl + hcol];
+                double s = L[hcol * ldl + p0 + i];          // (h is the last row: entry (p0 + i, h) of the symmetric sub-tableau)
                 for (int x = 0; x < i; ++x) s -= Cb[i * B + x] * vb[x];
                 vb[i] = s / Cb[i * B + i];
                 quad += vb[i] * vb[i];
@@ -150,26 +154,37 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             for (int e = tid; e < nl * B; e += nthr) {    // Tm = L[:,p] Cinv
                 const int i = e / B, x = e % B;
                 double s = 0.0;
-                for (int y = 0; y < B; ++y) s += L[i * ldl + p0 + y] * Cinv[y * B + x];
+                for (int y = 0; y < B; ++y) s += Ls(i, p0 + y) * Cinv[y * B + x];
                 Tm[e] = s;
             }
             __syncthreads();
             for (int e = tid; e < nl * B; e += nthr) {    // pivot rows -> LDS
                 const int x = e / nl, j = e % nl;
-                Prow[e] = L[(p0 + x) * ldl + j];
+                Prow[e] = Ls(p0 + x, j);
             }
             __syncthreads();
             // non-pivot entries: the sub-tableau lives in global memory (L2), so the read-modify-writes are issued in batches of
             // 8 independent loads per thread instead of one dependent load/store at a time
-            for (int e0 = tid; e0 < nl * nl; e0 += nthr * 8) {
+            // (lower triangle only, folded into a rectangle so that an element's (i, j) costs one division as before: row r of the
+            // rectangle is row nl-1-r of the triangle followed by row r-1 (nl odd) or r (nl even))
+            const bool odd = nl & 1;
+            const int wdt = odd ? nl : nl + 1, ntri = wdt * (odd ? (nl + 1) / 2 : nl / 2);
+            for (int e0 = tid; e0 < ntri; e0 += nthr * 8) {
                 double old_[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { const int e = e0 + q * nthr; old_[q] = (e < nl * nl) ? L[(e / nl) * ldl + e % nl] : 0.0; }
+                int ii[8], jj[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int e = e0 + q * nthr;
-                    if (e >= nl * nl) continue;
-                    const int i = e / nl, j = e % nl;
+                    const int r = e / wdt, c = e - r * wdt, first = nl - r;
+                    const int i = c < first ? nl - 1 - r : (odd ? r - 1 : r);
+                    ii[q] = i; jj[q] = c < first ? c : c - first;
+                    old_[q] = (e < ntri) ? L[i * ldl + jj[q]] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * nthr;
+                    if (e >= ntri) continue;
+                    const int i = ii[q], j = jj[q];
                     if ((i >= p0 && i < p0 + B) || (j >= p0 && j < p0 + B)) continue;
                     double sum = 0.0;
                     for (int x = 0; x < B; ++x) sum += Tm[i * B + x] * Prow[x * nl + j];
@@ -180,8 +195,8 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             const double sg = (flip_sign > 0) ? 1.0 : -1.0;
             for (int e = tid; e < nl * B; e += nthr) {    // pivot rows / columns
                 const int i = e / B, x = e % B;
-                if (i >= p0 && i < p0 + B) { L[i * ldl + p0 + x] = -Cinv[(i - p0) * B + x]; }
-                else { const double val = sg * Tm[e]; L[i * ldl + p0 + x] = val; L[(p0 + x) * ldl + i] = val; }
+                if (i >= p0 && i < p0 + B) { if (p0 + x <= i) L[i * ldl + p0 + x] = -Cinv[(i - p0) * B + x]; }
+                else { const double val = sg * Tm[e]; if (i > p0 + x) L[i * ldl + p0 + x] = val; else L[(p0 + x) * ldl + i] = val; }
             }
             __syncthreads();
         }
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             double v = 0.0;
             if (q < cnt && r < cnt) {
                 const double sq = (double)s_flipped[s_loc[q] / B], sr = (double)s_flipped[s_loc[r] / B];
-                v = -sq * sr * L[s_loc[q] * ldl + s_loc[r]];
+                v = -sq * sr * Ls(s_loc[q], s_loc[r]);
             }
             Gn[e] = v;
         }

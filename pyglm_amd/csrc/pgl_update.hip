@@ -1,6 +1,6 @@
 // Batched rank-k updates  C[b] = beta C[b] + alpha A[b]' B[b]  on the fp64 MFMA, for the two places of the sweep that are made of them:
 //   * the collapsed flips (pyglm/regression.py:282-320 as a sweep tableau, pgl_flips.hip): M -= W'U over the lower triangle of every
-//     neuron's tableau, rank 512 in the initial sweep, rank <= 240 after a proposal window, and W = G U in front of it;
+//     neuron's tableau, rank 512 in the initial sweep, rank <= 320 after a proposal window, and W = G U in front of it;
 //   * the blocked Cholesky of the weight draw (pyglm/regression.py:323-340, pgl_chol.hip): the rank-256 trailing updates (upper form).
 // These are short-K, read-modify-write products on per-neuron operands: an output tile lives for K / 16 K tiles only, its operand panels
 // belong to one neuron, and C itself streams through HBM once per pass.  The generic kernel of pgl_gemm.hip (128 x 128 tiles, register

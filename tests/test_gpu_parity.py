@@ -399,7 +399,7 @@ def test_sweep_vs_oracle_large_initial_active_set(torch_dev):
 
 def test_visit_order_and_plain_tableau_agree(torch_dev):
     """the tableau in proposal order with trailing-only window updates (default) and the plain one (J's order, full updates) take
-    the same decisions and draw the same weights; several windows (N = 150 > 48 blocks per window at B = 5)"""
+    the same decisions and draw the same weights; several windows (N = 150 > 64 blocks per window at B = 5)"""
     from pyglm_amd.engine import make_draws
     N, B, T = 150, 5, 2500
     basis, X, Y, rng = _random_problem(N, B, T, seed=9)
@@ -459,7 +459,7 @@ def test_sharded_equals_unsharded(torch_dev, gram):
                                       (50, 5, 400, 1.0)])
 def test_edge_shapes_vs_oracle(torch_dev, N, B, T, rho):
     """edges: a single neuron, T below one 16-row K tile / not a multiple of 16, the reference's default B = 10, the
-    largest supported B (= 32: 7 blocks per proposal window), rho = 0 everywhere (deterministic: all connections off), and two all-on
+    largest supported B (= 32: 10 blocks per proposal window), rho = 0 everywhere (deterministic: all connections off), and two all-on
     cases whose active dimension (74, 251) ends a few rows into a 64-row Cholesky sub-panel with the padded leading dimension (80, 256)
     shorter than the sub-panel: a strip update must not write past a neuron's own rows"""
     from pyglm_amd.engine import make_draws
