@@ -78,10 +78,17 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
     __shared__ double oms[WEIGHTED ? CH : 1][WEIGHTED ? G : 1];
     const int tid = threadIdx.x, cl = tid % CS_COLS, tl = tid / CS_COLS, c = blockIdx.x * CS_COLS + cl;
     const bool live = c < D;
+    // gridDim.y > 1: the time axis in gridDim.y chunks (multiples of CH bins), chunk y's statistics at amax / ss + y G D (folded in chunk order
+    // by i8_scales_kernel): 320 column blocks alone are one and a quarter workgroups per CU, each walking all of T -- 2.8 TB/s
+    const int tchunk = ((T + (int)gridDim.y - 1) / (int)gridDim.y + CH - 1) / CH * CH;
+    const int tbeg = (int)blockIdx.y * tchunk;
+    T = T < tbeg + tchunk ? T : tbeg + tchunk;
+    amax += (long)blockIdx.y * G * D;
+    ss += (long)blockIdx.y * G * D;
     double m[G], q[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { m[g] = 0.0; q[g] = 0.0; }
-    for (int t0 = 0; t0 < T; t0 += CH) {
+    for (int t0 = tbeg; t0 < T; t0 += CH) {
         if (WEIGHTED) {
             __syncthreads();
             for (int e = tid; e < CH * G; e += CS_COLS * CS_LANES) {
@@ -129,10 +136,12 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void i8_colstats_kernel(const d
 // rounds every occurrence of a repeated value the same way and those errors add up coherently (measured: 5x the random-rounding model
 // on basis-filtered spikes, up to sqrt(T) x on binary columns).  1 for an empty column, NaN for a non-finite one.
 __global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict__ amax, const double* __restrict__ ss, long n, double limit,
-                                                        double* __restrict__ scale) {
+                                                        double* __restrict__ scale, int nch) {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const double a = amax[k], nrm = sqrt(ss[k]) * (1.0 + 1e-12);        // (summation error of ss: never let it loosen the bound)
+    double a = amax[k], sq = ss[k];
+    for (int y = 1; y < nch; ++y) { a = fmax(a, amax[y * n + k]); sq += ss[y * n + k]; }      // time chunks of the statistics pass, in order
+    const double nrm = sqrt(sq) * (1.0 + 1e-12);                        // (summation error of ss: never let it loosen the bound)
     double s = 1.0;
     if (!(a < HUGE_VAL) || !(nrm < HUGE_VAL)) s = __builtin_nan("");
     else if (a > 0.0) {
@@ -897,9 +906,33 @@ int pgl_k_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int
     return PGL_OK;
 }
 
+// statistics + scales of omega_g X in one go, the time axis cut into NCH chunks so that the pass fills the chip: scratch holds 2 NCH G D doubles
+// (partial maxima, then partial sums of squares).  The sums are formed in a fixed order (per chunk as in pgl_k_i8_colstats, then over the
+// chunks), so the scales do not depend on launch timing; they can differ from pgl_k_i8_colstats + pgl_k_i8_scales in the last bit of a norm,
+// i.e. only for a column whose norm sits on a power-of-two boundary.
+constexpr int CS_NCH = 4;
+size_t pgl_k_i8_stats_scratch_doubles(int D, int G) { return (size_t)2 * CS_NCH * G * D; }
+int pgl_k_i8_colstats_scales(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, int nplanes, double* scratch, double* scale,
+                             hipStream_t st) {
+    if (G > CS_G || G < 1 || !Om) { pgl_set_error("i8 colstats+scales: %d weight columns per call (max %d)", G, CS_G); return PGL_ERR_ARG; }
+    if (pgl_k_i8_nu(nplanes, T) < 8) { pgl_set_error("i8 scales: %d moduli leave no room for T = %d", nplanes, T); return PGL_ERR_ARG; }
+    const int nch = T >= 4096 ? CS_NCH : 1;
+    double* pm = scratch;
+    double* pq = scratch + (size_t)CS_NCH * G * D;
+    const dim3 grid((D + CS_COLS - 1) / CS_COLS, nch), block(CS_COLS * CS_LANES);
+#define PGL_CS2(g_) case g_: hipLaunchKernelGGL((i8_colstats_kernel<g_, true>), grid, block, 0, st, X, ldx, Om, ldo, T, D, pm, pq); break;
+    switch (G) { PGL_CS2(1) PGL_CS2(2) PGL_CS2(3) PGL_CS2(4) PGL_CS2(5) PGL_CS2(6) PGL_CS2(7) PGL_CS2(8) default: break; }
+#undef PGL_CS2
+    PGL_CHECK_LAUNCH();
+    const long n = (long)G * D;
+    hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pm, pq, n, pgl_k_i8_norm_limit(nplanes, T), scale, nch);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
 int pgl_k_i8_scales(const double* amax, const double* ss, long n, int T, int nplanes, double* scale, hipStream_t st) {
     if (pgl_k_i8_nu(nplanes, T) < 8) { pgl_set_error("i8 scales: %d moduli leave no room for T = %d", nplanes, T); return PGL_ERR_ARG; }
-    hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amax, ss, n, pgl_k_i8_norm_limit(nplanes, T), scale);
+    hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amax, ss, n, pgl_k_i8_norm_limit(nplanes, T), scale, 1);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

@@ -261,8 +261,16 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     const int gz = G < nbb - g0 ? G : nbb - g0;
                     const double* om = d.OK + s0 + g0;
                     auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
-                    RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
-                    RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
+                    // (the statistics pass borrows the residue buffer for its per-chunk partials: the previous group's CRT has read it, this
+                    // group's products have not written it yet)
+                    static const bool split_t = [] { const char* e = getenv("PGL_I8_STATS_SPLIT"); return !(e && e[0] == '0'); }();     // A/B switch
+                    const size_t r_bytes = (size_t)gz * np * pgl_k_i8_padded_rows((int)D) * pgl_k_i8_padded_rows((int)D);
+                    if (split_t && pgl_k_i8_stats_scratch_doubles((int)D, gz) * sizeof(double) <= r_bytes)
+                        RC(pgl_k_i8_colstats_scales(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, np, reinterpret_cast<double*>(s->i8_R), sB, st));
+                    else {
+                        RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
+                        RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
+                    }
                     clk.toc(m);
                     // time slices (BASELINE configs[4]: one neuron's planes are 86 GB): the integer Gram is a sum over time, so the
                     // slices' products add up in the residues; a data set without resident X planes converts those per slice too
