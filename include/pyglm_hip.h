@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 6
+#define PGL_ABI_VERSION 7
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -220,6 +220,8 @@ typedef struct {
     const double* sA;              /* [D] column scales of X (pgl_i8_scales) */
     const void* PA;                /* residue planes of X (pgl_i8_planes), `planes` of them; NULL: converted per time slice into pgl_sweep_t.i8_PAs */
     const double* omega_override;  /* optional [T][nloc]: replaces the PG draws (test hook: the reference fixtures inject omega) */
+    const double* xmax;            /* optional [D]: max_t |X[t][d]| (the column maxima pgl_i8_colstats gives for Om = NULL).  With it and
+                                    * pgl_sweep_t.i8_norm the scales of omega_n X are taken for a whole batch of neurons at once (see there) */
 } pgl_dataset_t;
 
 #define PGL_NSTAGES 16
@@ -266,6 +268,12 @@ typedef struct {
                                     * residue plane into four K quarters, which evens out its final rounds (13 x 136 items per XCD of 32 CUs at
                                     * BASELINE configs[2]: 55.25 rounds -> 51 + 17/4); the quarters' residues are added by the CRT.  NULL: no split.
                                     * Exact integer arithmetic either way: the same J to the last bit */
+    double* i8_norm;               /* optional scratch, (nb rounded up to even) * Dp + nloc doubles.  With it (and pgl_dataset_t.xmax) the norms
+                                    * the integer Gram scales the columns of omega_n X from are ONE fp64 MFMA contraction of the squared operands
+                                    * per batch of nb neurons, and the largest element of a column is bounded by max_t omega_nt * xmax[d]: X is
+                                    * read once per batch instead of once per group of 8 neurons.  The scales can only come out SMALLER than
+                                    * from the exact column statistics (a column that one element dominates loses a bit or two of its 50);
+                                    * NULL: pgl_i8_colstats per group */
     int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
                                     * this GPU (bench.py scaling_proxy); the state of the others is left alone */
     /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */

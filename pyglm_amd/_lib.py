@@ -24,7 +24,7 @@ class CholState(ctypes.Structure):   # pgl_chol_t
 
 class Dataset(ctypes.Structure):     # pgl_dataset_t
     _fields_ = [("T", c_i), ("Tp", c_i), ("X", c_p), ("Xt", c_p), ("Y", c_p), ("Psi", c_p), ("OK", c_p), ("llpart", c_p), ("elem0", c_u64),
-                ("int8", c_i), ("planes", c_i), ("sA", c_p), ("PA", c_p), ("omega_override", c_p)]
+                ("int8", c_i), ("planes", c_i), ("sA", c_p), ("PA", c_p), ("omega_override", c_p), ("xmax", c_p)]
 
 
 NSTAGES = 16
@@ -42,7 +42,7 @@ class Sweep(ctypes.Structure):       # pgl_sweep_t
                 ("Wt", c_p), ("bias", c_p), ("border", c_p), ("skip", c_p), ("c0_dense", c_p),
                 ("Jbuf", c_p), ("Mtab", c_p), ("Ac", c_p), ("hc", c_p), ("Tinv", c_p), ("G", c_p), ("Lws", c_p), ("Ut", c_p), ("Wt_ws", c_p),
                 ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("act", c_p), ("na", c_p),
-                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p), ("i8_slice", c_i), ("i8_PAs", c_p), ("i8_Rx", c_p), ("nrun", c_i),
+                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p), ("i8_slice", c_i), ("i8_PAs", c_p), ("i8_Rx", c_p), ("i8_norm", c_p), ("nrun", c_i),
                 ("all_deterministic", c_i), ("init_rows_bound", c_i), ("active_rows_bound", c_i), ("times", ctypes.POINTER(StageTimes))]
 
 
@@ -93,7 +93,7 @@ SIGNATURES = {
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

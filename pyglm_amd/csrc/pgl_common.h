@@ -65,7 +65,7 @@ struct PglGemmArgs {
     int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed;  3: M = min(g.M, d), N = d
     int pipe;                                  // 1: a rank-k product of the flips / the Cholesky: may take the update pipeline (pgl_update.hip) where that is faster; 2: must
 };
-enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2 };
+enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2, PGL_GEMM_SQUARES = 3 };   // SQUARES: PLAIN on the squared elements of A and B
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
 // the update pipeline (pgl_update.hip): 256 x 128 tiles, DMA-staged, persistent; pgl_launch_gemm routes products marked `pipe` to it
 bool pgl_update_supported(const PglGemmArgs& a);
@@ -108,6 +108,8 @@ int pgl_k_i8_nu(int, int);
 double pgl_k_i8_norm_limit(int, int);
 int pgl_k_i8_colstats(const double*, long, const double*, long, int, int, int, double*, double*, hipStream_t);
 int pgl_k_i8_scales(const double*, const double*, long, int, int, double*, hipStream_t);
+int pgl_k_i8_colmax(const double*, long, int, int, double*, hipStream_t);
+int pgl_k_i8_scales_bound(const double*, long, const double*, const double*, int, int, int, int, double*, hipStream_t);
 size_t pgl_k_i8_stats_scratch_doubles(int, int);
 int pgl_k_i8_colstats_scales(const double*, long, const double*, long, int, int, int, int, double*, double*, hipStream_t);
 int pgl_k_i8_planes(const double*, long, int transposed, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);

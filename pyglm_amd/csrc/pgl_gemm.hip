@@ -62,7 +62,9 @@ __device__ __forceinline__ void block_sync_lds() {
 // CINIT (2-stage pipeline, alpha = +-1, beta = 1): the accumulators START from the C tile (loads issued together with the first K
 // tile, so their latency overlaps the pipeline fill) and the epilogue only stores.  The rank-k tableau / Cholesky updates are
 // short (K = 128..320) read-modify-write items whose serial epilogue loads cost as much as a third of the MFMA time.
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA = false, bool CINIT = false>
+// SQ: both operands are squared element by element on their way to LDS -- C = sum_k A[k][m]^2 B[k][n]^2, the sums of squares of the columns of
+// omega_n X for a whole batch of neurons as ONE contraction (the norms the integer Gram scales its operands from, pgl_sweep.hip)
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool DMA = false, bool CINIT = false, bool SQ = false>
 __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, double* smem) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     const int ntm = (g.M + C::BM - 1) / C::BM;
@@ -153,13 +155,13 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 #pragma unroll
         for (int i = 0; i < C::A_LD; ++i) {
             const int p = tid + i * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-            if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = signed_a(ra[i]);
-            else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[i];
+            if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = signed_a(SQ ? ra[i] * ra[i] : ra[i]);
+            else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = SQ ? ra[i] * ra[i] : ra[i];
         }
 #pragma unroll
         for (int i = 0; i < C::B_LD; ++i) {
             const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
-            *reinterpret_cast<d2_t*>(Bs + r * C::SB + c) = rb[i];
+            *reinterpret_cast<d2_t*>(Bs + r * C::SB + c) = SQ ? rb[i] * rb[i] : rb[i];
         }
         if (WEIGHTED && tid < BK * WZ) (Bs + C::B_ELEMS)[tid] = rw;
     };
@@ -234,12 +236,12 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 double* Bs = As + C::A_ELEMS;
                 if (q < C::A_LD) {
                     const int p = tid + q * C::THREADS, r = p / (C::BM / 2), c = (p % (C::BM / 2)) * 2;
-                    if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = signed_a(ra[q]);
-                    else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = ra[q];
+                    if constexpr (CINIT) *reinterpret_cast<d2_t*>(As + r * C::SA + c) = signed_a(SQ ? ra[q] * ra[q] : ra[q]);
+                    else *reinterpret_cast<d2_t*>(As + r * C::SA + c) = SQ ? ra[q] * ra[q] : ra[q];
                 } else {
                     const int i = q - C::A_LD;
                     const int p = tid + i * C::THREADS, r = p / (C::BN / 2), c = (p % (C::BN / 2)) * 2;
-                    *reinterpret_cast<d2_t*>(Bs + r * C::SB + c) = rb[i];
+                    *reinterpret_cast<d2_t*>(Bs + r * C::SB + c) = SQ ? rb[i] * rb[i] : rb[i];
                 }
             };
             auto kstep = [&](int buf, int kk, auto hook) {
@@ -477,7 +479,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 
 // ---- plain launch: one workgroup per work item, XCD-aware order (block b runs on XCD b % 8: consecutive slots of one XCD
 // walk the batch index of the same tile, so co-resident workgroups share operand panels through that XCD's L2)
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool CINIT = false>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES, bool CINIT = false, bool SQ = false>
 __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(WM* WN* WZ * 64, 2) void gemm_tn_f64(PglGemmArgs g)
     const long chunk = (total + 7) / 8;
     long w = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((long)(blockIdx.x >> 3) >= chunk || w >= total) return;
-    gemm_item<WM, WN, WZ, WEIGHTED, STAGES, false, CINIT>(g, w, smem);
+    gemm_item<WM, WN, WZ, WEIGHTED, STAGES, false, CINIT, SQ>(g, w, smem);
 }
 
 // ---- persistent launch (long launches: the hardware dispatcher's round-robin drifts after a few hundred rounds and the
@@ -705,14 +707,14 @@ __global__ __launch_bounds__(256, 2) void gram_fine_persistent(PglGemmArgs g) {
     }
 }
 
-template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2, bool CINIT = false>
+template <int WM, int WN, int WZ, bool WEIGHTED, int STAGES = 2, bool CINIT = false, bool SQ = false>
 int launch(const PglGemmArgs& a, hipStream_t st) {
     using C = Cfg<WM, WN, WZ, WEIGHTED, STAGES>;
     if constexpr (!WEIGHTED && STAGES == 2 && !CINIT) {
-        if (a.beta == 1.0 && (a.alpha == 1.0 || a.alpha == -1.0)) return launch<WM, WN, WZ, WEIGHTED, STAGES, true>(a, st);
+        if (a.beta == 1.0 && (a.alpha == 1.0 || a.alpha == -1.0)) return launch<WM, WN, WZ, WEIGHTED, STAGES, true, SQ>(a, st);
     }
     static PglPerDevice attr_set;
-    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED, STAGES, CINIT>;
+    auto kern = gemm_tn_f64<WM, WN, WZ, WEIGHTED, STAGES, CINIT, SQ>;
     if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, attr_set)) return rc;
     const int ntm = (a.M + C::BM - 1) / C::BM, ntn = (a.N + C::BN - 1) / C::BN;
     const long ntiles = a.tri ? (long)ntm * (ntm + 1) / 2 : (long)ntm * ntn;
@@ -816,6 +818,7 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
+        case PGL_GEMM_SQUARES: PGL_CHECK_ARG(a.tri == 0 && !a.pipe); return launch<2, 4, 1, false, 2, false, true>(a, st);
         case PGL_GEMM_TRI1: {
             PGL_CHECK_ARG(a.M == a.N);
             // a lower triangle whose last few rows would open a tile row of their own (a tableau: D + 2 rows, 41 of 861 tiles for the bias and

@@ -156,6 +156,47 @@ __global__ __launch_bounds__(256) void i8_scales_kernel(const double* __restrict
     scale[k] = s;
 }
 
+// ---- the same scales for a whole batch of neurons without a pass over X per group (pgl_sweep.hip): the sums of squares of the columns of
+// omega_n X come from ONE fp64 MFMA contraction per batch, ss[n][d] = sum_t omega_nt^2 x_td^2 (PGL_GEMM_SQUARES), and the largest element is
+// replaced by the bound max_t omega_nt * max_t |x_td| (and by the norm itself, whichever is smaller).  Both only ever make a scale SMALLER than
+// the exact statistics would, so every range argument above holds; the element bound matters only for a column that one element dominates
+// (|v|_max > 0.59 |v|_2 with 13 moduli).  The products of squares are rounded differently from the squares of the rounded products the planes
+// kernel forms and the MFMA sums them sequentially: relative (T + 16) 2^-53 at most, which the norm is inflated by before it is used.
+__global__ __launch_bounds__(256) void i8_colmax_kernel(const double* __restrict__ Om, long ldo, int T, int n, unsigned long long* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int per = (T + (int)gridDim.y - 1) / (int)gridDim.y, t0 = (int)blockIdx.y * per, t1 = min(T, t0 + per);
+    unsigned long long m = 0ull;
+    for (int t = t0; t < t1; ++t) {
+        const unsigned long long v = (unsigned long long)__double_as_longlong(Om[(long)t * ldo + c]) & 0x7fffffffffffffffull;   // |.|: ordered like the integers
+        m = v > m ? v : m;                                                                                                  // (a NaN sorts above every number)
+    }
+    atomicMax(&out[c], m);               // a maximum does not depend on the order it is taken in
+}
+
+__global__ __launch_bounds__(256) void i8_scales_bound_kernel(const double* __restrict__ ss, long ldss, const double* __restrict__ ommax,
+                                                              const double* __restrict__ xmax, int D, int G, double limit, double inflate,
+                                                              double* __restrict__ scale) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (long)G * D) return;
+    const int g = (int)(k / D), d = (int)(k % D);
+    const double sq = ss[(long)g * ldss + d];
+    const double nrm = sqrt(sq) * inflate;
+    const double bound = ommax[g] * xmax[d];
+    const double a = bound < nrm ? bound : nrm;          // (a NaN / inf anywhere in the column shows in sq)
+    double s = 1.0;
+    if (!(nrm < HUGE_VAL)) s = __builtin_nan("");
+    else if (a > 0.0) {
+        int ea, en, el;
+        (void)frexp(a, &ea);
+        const double mn = frexp(nrm, &en), ml = frexp(limit, &el);
+        const int e_norm = el - en - (mn > ml ? 1 : 0);
+        const int e = min(ELEM_BITS - ea, e_norm);
+        s = ldexp(1.0, e);
+    }
+    scale[k] = s;
+}
+
 // ------------------------------------------------------------------ fp64 -> residue planes
 struct PlaneArgs {
     const double* X; long ldx;            // [T][ldx], or (transposed != 0) the transposed copy [D][ldx]
@@ -926,6 +967,26 @@ int pgl_k_i8_colstats_scales(const double* X, long ldx, const double* Om, long l
     PGL_CHECK_LAUNCH();
     const long n = (long)G * D;
     hipLaunchKernelGGL(i8_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pm, pq, n, pgl_k_i8_norm_limit(nplanes, T), scale, nch);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+// largest |omega| per weight column: out[c] (bit pattern of a non-negative double) for the n columns of Om, zeroed here
+int pgl_k_i8_colmax(const double* Om, long ldo, int T, int n, double* out, hipStream_t st) {
+    if (hipMemsetAsync(out, 0, (size_t)n * sizeof(double), st) != hipSuccess) { pgl_set_error("memset failed"); return PGL_ERR_HIP; }
+    hipLaunchKernelGGL(i8_colmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(T >= 8192 ? 128 : 1)), dim3(256), 0, st, Om, ldo, T, n,
+                       reinterpret_cast<unsigned long long*>(out));
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
+// scales of G weight columns from their sums of squares ss[g][d] (leading dimension ldss) and the element bound ommax[g] * xmax[d]
+int pgl_k_i8_scales_bound(const double* ss, long ldss, const double* ommax, const double* xmax, int D, int G, int T, int nplanes, double* scale,
+                          hipStream_t st) {
+    if (pgl_k_i8_nu(nplanes, T) < 8) { pgl_set_error("i8 scales: %d moduli leave no room for T = %d", nplanes, T); return PGL_ERR_ARG; }
+    const long n = (long)G * D;
+    hipLaunchKernelGGL(i8_scales_bound_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ss, ldss, ommax, xmax, D, G,
+                       pgl_k_i8_norm_limit(nplanes, T), 1.0 + ((double)T + 16.0) * 1.2e-16, scale);
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }

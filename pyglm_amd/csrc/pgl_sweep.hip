@@ -257,19 +257,63 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 double* amax = s->i8_stat;
                 double* ss = s->i8_stat + (long)G * D;
                 double* sB = s->i8_stat + 2L * G * D;
+                // The scales of omega_n X need the norm of each of its columns.  With d.xmax and s->i8_norm those come for the WHOLE batch from one
+                // fp64 MFMA contraction of the squared operands, ss[n][j] = sum_t omega_nt^2 x_tj^2 -- X is read once per batch instead of once
+                // per group of 8 neurons (215 ms of column-statistics passes per sweep at BASELINE configs[2]) --, T cut into slices whose partial
+                // sums borrow the (idle) residue buffer and are added in slice order, like the border sums above.
+                static const bool norm_gemm = [] { const char* e = getenv("PGL_I8_NORM_GEMM"); return !(e && e[0] == '0'); }();     // A/B switch
+                const bool batch_norms = norm_gemm && d.xmax && s->i8_norm && s0 % 2 == 0;
+                const long part = (long)r_up(s->nb, 2) * Dp;
+                double* ssb = s->i8_norm;                          // [nb rounded up to even][Dp] sums of squares of this batch's columns
+                double* ommax = s->i8_norm + part;                 // [nloc] largest omega of every local neuron
+                if (batch_norms) {
+                    auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
+                    RC(pgl_k_i8_colmax(d.OK + s0, 2 * ldn, d.T, nbb, ommax + s0, st));
+                    const int Mp = r_up(nbb, 2);
+                    const long tiles = (long)((Mp + 127) / 128) * ((D + 255) / 256);
+                    const size_t r_bytes = (size_t)(G < nbb ? G : nbb) * np * pgl_k_i8_padded_rows((int)D) * pgl_k_i8_padded_rows((int)D);
+                    long S = 2L * pgl_device_cus(pgl_device()) / tiles;
+                    if (S > 64) S = 64;
+                    if (S > d.Tp / 256) S = d.Tp / 256;
+                    if (S > (long)(r_bytes / sizeof(double)) / part) S = (long)(r_bytes / sizeof(double)) / part;
+                    PglGemmArgs q{};
+                    q.A = d.OK + s0; q.lda = 2 * ldn; q.a_cols = Mp;
+                    q.B = d.X; q.ldb = Dp; q.b_cols = Dp;
+                    q.M = Mp; q.N = (int)D; q.alpha = 1.0; q.beta = 0.0; q.tri = 0; q.ldc = Dp;
+                    if (S >= 2) {
+                        const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
+                        double* partial = reinterpret_cast<double*>(s->i8_R);
+                        q.strideA = (long)chunk * q.lda; q.strideB = (long)chunk * Dp; q.C = partial; q.strideC = part; q.K = chunk; q.nbatch = (int)S;
+                        RC(pgl_launch_gemm(PGL_GEMM_SQUARES, q, st));
+                        if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
+                            q.A += (long)S * chunk * q.lda; q.B += (long)S * chunk * Dp; q.K = rem; q.nbatch = 1; q.beta = 1.0;
+                            RC(pgl_launch_gemm(PGL_GEMM_SQUARES, q, st));
+                        }
+                        hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, partial, part, (int)S, ssb, 0, Dp, (int)D);
+                        PGL_CHECK_LAUNCH();
+                    } else {
+                        q.C = ssb; q.K = d.Tp; q.nbatch = 1;
+                        RC(pgl_launch_gemm(PGL_GEMM_SQUARES, q, st));
+                    }
+                    clk.toc(m);
+                }
                 for (int g0 = 0; g0 < nbb; g0 += G) {
                     const int gz = G < nbb - g0 ? G : nbb - g0;
                     const double* om = d.OK + s0 + g0;
-                    auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
-                    // (the statistics pass borrows the residue buffer for its per-chunk partials: the previous group's CRT has read it, this
-                    // group's products have not written it yet)
-                    static const bool split_t = [] { const char* e = getenv("PGL_I8_STATS_SPLIT"); return !(e && e[0] == '0'); }();     // A/B switch
-                    const size_t r_bytes = (size_t)gz * np * pgl_k_i8_padded_rows((int)D) * pgl_k_i8_padded_rows((int)D);
-                    if (split_t && pgl_k_i8_stats_scratch_doubles((int)D, gz) * sizeof(double) <= r_bytes)
-                        RC(pgl_k_i8_colstats_scales(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, np, reinterpret_cast<double*>(s->i8_R), sB, st));
-                    else {
-                        RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
-                        RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
+                    auto m = clk.tic(ST_STATS, batch_norms ? 0.0 : 8.0 * d.T * D);
+                    if (batch_norms) {
+                        RC(pgl_k_i8_scales_bound(ssb + (long)g0 * Dp, Dp, ommax + s0 + g0, d.xmax, (int)D, gz, d.T, np, sB, st));
+                    } else {
+                        // one pass over X per group (the statistics pass borrows the residue buffer for its per-chunk partials: the previous
+                        // group's CRT has read it, this group's products have not written it yet)
+                        static const bool split_t = [] { const char* e = getenv("PGL_I8_STATS_SPLIT"); return !(e && e[0] == '0'); }();     // A/B switch
+                        const size_t r_bytes = (size_t)gz * np * pgl_k_i8_padded_rows((int)D) * pgl_k_i8_padded_rows((int)D);
+                        if (split_t && pgl_k_i8_stats_scratch_doubles((int)D, gz) * sizeof(double) <= r_bytes)
+                            RC(pgl_k_i8_colstats_scales(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, np, reinterpret_cast<double*>(s->i8_R), sB, st));
+                        else {
+                            RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
+                            RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
+                        }
                     }
                     clk.toc(m);
                     // time slices (BASELINE configs[4]: one neuron's planes are 86 GB): the integer Gram is a sum over time, so the

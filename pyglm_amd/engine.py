@@ -156,6 +156,7 @@ class GibbsEngine(object):
         self.logodds = None
         self.profile = False            # True: every stage of pgl_sweep is timed with HIP events; a collection of stage names: only those
         self._times = None              # pgl_stage_times_t filled by pgl_sweep while `profile` is on
+        self._i8_norm = None            # integer Gram: per-batch sums of squares of the columns of omega_n X + the largest omega per neuron
         self._ev = []
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
@@ -319,6 +320,9 @@ class GibbsEngine(object):
             ds.sA = self._z(self.D)
             call("pgl_i8_colstats", ptr(ds.X), self.Dp, None, 0, T, self.D, 1, ptr(stat[0]), ptr(stat[1]), st)
             call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), self.D, T, ds.planes, ptr(ds.sA), st)
+            ds.xmax = stat[0]               # column maxima of X: with _i8_norm, the sweep takes the norms of omega_n X per batch (pgl_sweep_t.i8_norm)
+            if self._i8_norm is None:
+                self._i8_norm = self._z((self.nb + 2) * self.Dp + self.nloc + 2)
             ds.PA = None
             if plan["resident"]:
                 ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
@@ -424,8 +428,9 @@ class GibbsEngine(object):
         ds = self.datasets[i]
         if ds.int8:
             ds.int8 = False
-            ds.PA = ds.sA = None
+            ds.PA = ds.sA = ds.xmax = None
             if not any(getattr(d, "int8", False) for d in self.datasets):
+                self._i8_norm = None
                 self._i8_scratch = None             # nobody multiplies planes any more: the group buffers (56 GB at cfg3) go back too
             torch.cuda.empty_cache()
 
@@ -543,7 +548,8 @@ class GibbsEngine(object):
                 ov = torch.from_numpy(np.ascontiguousarray(omega_override[i], dtype=np.float64).reshape(ds.T, nloc)).to(self.dev)
                 keep.append(ov)
             dsets[i] = _lib.Dataset(ds.T, ds.Tp, ptr(ds.X), ptr(ds.Xt), ptr(ds.Y), ptr(ds.Psi), ptr(ds.OK), ptr(ds.llpart), ds.elem0, int(ds.int8),
-                                    int(getattr(ds, "planes", 0) or 0), ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)), ptr(ov))
+                                    int(getattr(ds, "planes", 0) or 0), ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)), ptr(ov),
+                                    ptr(getattr(ds, "xmax", None)))
         i8 = self._i8_scratch
         if self.profile and self._times is None:
             self._times = _lib.StageTimes()
@@ -561,7 +567,7 @@ class GibbsEngine(object):
                         ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
                         ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
                         ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
-                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, int(nrun),
+                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, ptr(self._i8_norm) if i8 else None, int(nrun),
                         int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
                         ctypes.pointer(self._times) if self.profile else None)
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)

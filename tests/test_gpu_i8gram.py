@@ -395,6 +395,48 @@ def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("N,B,T,batch", [(70, 5, 2300, 70), (70, 5, 9000, 22), (33, 4, 2500, 7)])
+def test_batch_norms_give_the_scales_of_the_column_statistics(N, B, T, batch):
+    """Inside the sweep the norms of the columns of omega_n X come from one contraction of the squared operands per batch and the largest
+    element from the bound max omega * max |x| (pgl_sweep_t.i8_norm) instead of a pass over X per group of 8 neurons.  Scales are powers of
+    two, so on ordinary data both routes give the same scales and with them the same J and the same sweep, bit for bit; a column that a
+    single element dominates may get a smaller scale (never a larger one) -- then J still agrees to the integer path's accuracy.
+    Batches of odd size and a ragged last batch and group included."""
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    rng = np.random.default_rng(12)
+    D = N * B
+    Y = (rng.random((T, N)) < 0.1).astype(float)
+    X = rng.random((T, N, B)) * (rng.random((T, N, B)) < 0.3) * 0.2
+    X[7, 3, 1] = 40.0                         # one element that carries its whole column: the bound binds there
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
+    b = np.full(N, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * 4.0, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+    rho = np.full((N, N), 0.5)
+    perm, u, z = make_draws(5, 0, range(N), N, D)
+    eng = GibbsEngine(N, B, gram="int8", batch=batch)
+    ds = eng.add_data(Y, X=X)
+    assert ds.int8 and ds.xmax is not None and eng._i8_norm is not None
+    res = []
+    for batch_norms in (True, False):
+        keep = eng._i8_norm
+        if not batch_norms:
+            eng._i8_norm = None               # -> pgl_sweep_t.i8_norm = NULL: pgl_i8_colstats per group
+        out = eng.sweep(a, W, b, rho, *hyp, perm, u, z, seed=5, sweep=0)
+        eng._i8_norm = keep
+        res.append((eng.Jbuf[:, :D + 2, :D + 2].cpu().numpy().copy(), out))
+    (J1, out1), (J0, out0) = res                # J of the LAST batch of each run
+    d = 3 * B + 1                               # the dominated column
+    other = np.ones(D + 2, dtype=bool)
+    other[d] = False
+    m = np.ix_(range(J1.shape[0]), other, other)
+    np.testing.assert_array_equal(np.tril(J1[m]), np.tril(J0[m]))
+    np.testing.assert_allclose(J1, J0, rtol=0, atol=1e-12 * np.abs(J0).max())
+    np.testing.assert_array_equal(out1[0], out0[0])                          # the same adjacency
+    for x, y in zip(out1[1:], out0[1:]):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-9)
+
+
 def test_auto_takes_the_integer_gram_where_it_pays():
     """gram='auto' (the default): int8 planes for large D and long T, the fp64 kernel for small shapes and for the Gaussian model"""
     from pyglm_amd.engine import GibbsEngine
