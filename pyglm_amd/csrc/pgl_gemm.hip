@@ -818,7 +818,10 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
         case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
-        case PGL_GEMM_SQUARES: PGL_CHECK_ARG(a.tri == 0 && !a.pipe); return launch<2, 4, 1, false, 2, false, true>(a, st);
+        case PGL_GEMM_SQUARES:
+            PGL_CHECK_ARG(a.tri == 0 && !a.pipe);
+            if (a.M <= 64) return launch<1, 4, 1, false, 2, false, true>(a, st);      // few neurons per batch (BASELINE configs[4]: 4): 64-row tiles
+            return launch<2, 4, 1, false, 2, false, true>(a, st);
         case PGL_GEMM_TRI1: {
             PGL_CHECK_ARG(a.M == a.N);
             // a lower triangle whose last few rows would open a tile row of their own (a tableau: D + 2 rows, 41 of 861 tiles for the bias and
