@@ -515,34 +515,45 @@ __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
 // potential row D+1 stay last.  Once a window of positions has been proposed its rows are never read again, so the rank-k update after
 // window w only has to touch the trailing square from position (w+1) R on (pgl_k_flip_apply, window form) -- a third of the
 // full-tableau work summed over the windows -- and a window's sub-tableau is a contiguous diagonal square.
-// One workgroup moves one SOURCE block row mi (B rows of J, columns up to its diagonal block): the reads are coalesced row segments and
-// J is read exactly once; a thread owns one source column (block mj, offset y) and writes its B values either as B row segments of the
-// destination block (pos[mi], pos[mj]) or, when that block lies above the diagonal, as one contiguous run of its transpose
-// (pos[mj], pos[mi]).  blockIdx.y == N / N + 1: the bias and potential rows.  pos = inverse of perm, built in LDS per workgroup.
+// One workgroup builds one DESTINATION block row pi (the B rows of position pi, columns up to and including its diagonal block): a thread owns
+// a destination column, so every store is part of a coalesced row segment (the first version walked the SOURCE rows and scattered 40-byte
+// pieces -- partial-line writes, 37 ms per batch of 256 at BASELINE configs[2] against ~11 ms for a plain copy).  The reads gather: block
+// (pi, pj) is source block (mi, mj) = (perm[pi], perm[pj]) where mi >= mj -- B-double pieces of the B stored rows of block row mi, which this
+// workgroup ends up reading almost entirely -- and the transpose of (mj, mi) otherwise: B contiguous doubles of a row of block row mj per
+// thread.  blockIdx.y == N / N + 1: the bias and potential rows (columns gathered by position).
+// BT = B at compile time for the common block sizes (the B values of a block then live in registers and their loads are all in flight
+// together; with a run-time B they went through scratch one at a time: 36 ms per batch), 0 = any B.
+template <int BT>
 __global__ __launch_bounds__(256) void permute_tableau_kernel(FlipArgs g, const double* __restrict__ Jsrc, long lds_, long strideJ) {
-    extern __shared__ int s_pos[];              // [N]
-    const int n = blockIdx.z, N = g.N, B = g.B, D = N * B;
-    const int* perm = g.perm + (long)n * N;
-    const double* J = Jsrc + (long)n * strideJ;
-    double* M = g.M + (long)n * g.strideM;
-    for (int k = threadIdx.x; k < N; k += 256) s_pos[perm[k]] = k;
-    __syncthreads();
-    const int mi = blockIdx.y;
-    if (mi < N) {
-        const int pi = s_pos[mi], ncol = (mi + 1) * B;
+    const int n = blockIdx.z, N = g.N, B = BT ? BT : g.B, D = N * B;
+    const int* __restrict__ perm = g.perm + (long)n * N;
+    const double* __restrict__ J = Jsrc + (long)n * strideJ;
+    double* __restrict__ M = g.M + (long)n * g.strideM;
+    const int pi = blockIdx.y;
+    if (pi < N) {
+        const int mi = perm[pi], ncol = (pi + 1) * B;
         for (int c = threadIdx.x; c < ncol; c += 256) {
-            const int mj = c / B, y = c - mj * B, pj = s_pos[mj];
-            double v[32];
-            for (int x = 0; x < B; ++x) v[x] = tab_get(J, lds_, mi * B + x, c);      // (diagonal block: mirrored above its diagonal)
-            if (pi >= pj) { for (int x = 0; x < B; ++x) M[(long)(pi * B + x) * g.ldj + pj * B + y] = v[x]; }
-            else { for (int x = 0; x < B; ++x) M[(long)(pj * B + y) * g.ldj + pi * B + x] = v[x]; }
+            const int pj = c / B, y = c - pj * B, mj = perm[pj];
+            double v[BT ? BT : 32];
+            if (mi > mj) {
+#pragma unroll
+                for (int x = 0; x < B; ++x) v[x] = J[(long)(mi * B + x) * lds_ + mj * B + y];
+            } else if (mi < mj) {
+                const double* __restrict__ src = J + (long)(mj * B + y) * lds_ + mi * B;       // row of the mirrored block: B contiguous doubles
+#pragma unroll
+                for (int x = 0; x < B; ++x) v[x] = src[x];
+            } else {
+#pragma unroll
+                for (int x = 0; x < B; ++x) v[x] = tab_get(J, lds_, mi * B + x, mi * B + y);   // diagonal block: mirrored above its diagonal
+            }
+#pragma unroll
+            for (int x = 0; x < B; ++x) M[(long)(pi * B + x) * g.ldj + c] = v[x];
         }
     } else {
-        const int row = D + (mi - N);            // D: bias row, D + 1: potential row
+        const int row = D + (pi - N);            // D: bias row, D + 1: potential row
         for (int c = threadIdx.x; c <= row; c += 256) {
-            const double v = J[(long)row * lds_ + c];
-            const int pc = c < D ? s_pos[c / B] * B + c % B : c;
-            M[(long)row * g.ldj + pc] = v;
+            const int sc = c < D ? perm[c / B] * B + c % B : c;
+            M[(long)row * g.ldj + c] = J[(long)row * lds_ + sc];
         }
     }
 }
@@ -708,7 +719,13 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
 int pgl_k_flip_permute(const PglFlipState& s, const double* J, long ldjs, long strideJ, hipStream_t st) {
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, 0, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
                s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, 1, 0, s.logodds};
-    hipLaunchKernelGGL(permute_tableau_kernel, dim3(1, s.N + 2, s.nb), dim3(256), (size_t)s.N * sizeof(int), st, g, J, ldjs, strideJ);
+    const dim3 grid(1, s.N + 2, s.nb);
+#define PGL_PERMUTE(b_) case b_: hipLaunchKernelGGL(permute_tableau_kernel<b_>, grid, dim3(256), 0, st, g, J, ldjs, strideJ); break;
+    switch (s.B) {
+        PGL_PERMUTE(1) PGL_PERMUTE(2) PGL_PERMUTE(3) PGL_PERMUTE(4) PGL_PERMUTE(5) PGL_PERMUTE(6) PGL_PERMUTE(7) PGL_PERMUTE(8)
+        default: hipLaunchKernelGGL(permute_tableau_kernel<0>, grid, dim3(256), 0, st, g, J, ldjs, strideJ); break;
+    }
+#undef PGL_PERMUTE
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
