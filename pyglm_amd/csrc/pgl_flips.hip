@@ -55,10 +55,13 @@ struct FlipArgs {
 __device__ __forceinline__ double tab_get(const double* M, long ld, int i, int j) { return i >= j ? M[(long)i * ld + j] : M[(long)j * ld + i]; }
 
 // ------------------------------------------------------------------ proposals of one window, in LDS
+// BT = B at compile time for the common block sizes (0 = any B): the loops over a block unroll and the rank-B update of a flip runs on
+// register tiles.
+template <int BT>
 __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int N = g.N, B = g.B, D = N * B;
+    const int N = g.N, B = BT ? BT : g.B, D = N * B;
     const int k0 = window * g.R;
     const int nblk = min(g.R, N - k0);
     if (nblk <= 0 || (g.skip && g.skip[n])) { if (tid == 0) { g.d_cnt[n] = 0; g.batch_k[n] = 0; } return; }
@@ -67,13 +70,16 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     double* Tm = lds;                        // [nl][B]
     double* Prow = Tm + (size_t)nl * B;      // [B][nl]  pivot rows of the block being swept
     double* Cinv = Prow + (size_t)nl * B;    // [B][B]
-    double* Cb = Cinv + B * B;               // [B][B] cholesky scratch
-    double* vb = Cb + B * B;                 // [B]
-    __shared__ int s_flip, s_sign;
+    double* Cbs = Cinv + B * B;              // [R][B][B] Cholesky factor of every proposal's block
+    double* vbs = Cbs + (size_t)g.R * B * B; // [R][B]
+    __shared__ int s_flip, s_sign, s_first;
     __shared__ int s_flipped[KMAX];
 
     const double* M = g.M + (long)n * g.strideM;
     const int* perm = g.perm + (long)n * N;
+#ifdef PGL_DECIDE_TIMING
+    long long tq0 = wall_clock64(), tq_eval = 0, tq_flip = 0, tq_gather = 0, tq_rounds = 0, tq_flips = 0, tq1;
+#endif
     // the window's sub-tableau is symmetric: only its lower triangle (i >= j) is kept and updated -- half the read-modify-writes per flip
     for (int e = tid; e < nl * nl; e += nthr) {
         const int i = e / nl, j = e % nl;
@@ -86,9 +92,28 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     auto Ls = [&](int i, int j) { return i >= j ? L[i * ldl + j] : L[j * ldl + i]; };
 
     const int hcol = nl - 1;
-    for (int k = 0; k < nblk; ++k) {
-        const int m = perm[k0 + k], p0 = k * B;
-        if (tid == 0) {
+    // The proposals are sequential -- a flip changes the sub-tableau every later proposal reads -- but most do not flip (7-35 % do along
+    // the chain).  So all proposals not yet decided are EVALUATED at once, one per thread, from the current sub-tableau; the decisions up to
+    // and including the first flip are committed (they saw exactly the tableau the serial order would have shown them), that flip is
+    // applied by the whole workgroup, and the rest is evaluated again.  A window costs (flips + 1) evaluation rounds instead of one
+    // serial evaluation per proposal (64 of them, a dozen dependent L2 reads each); the decisions are the same function of the same numbers.
+    int k = 0;
+#ifdef PGL_DECIDE_TIMING
+    tq_gather = wall_clock64() - tq0;
+#endif
+    while (k < nblk) {
+#ifdef PGL_DECIDE_TIMING
+        tq1 = wall_clock64();
+#endif
+        if (tid == 0) s_first = nblk;
+        __syncthreads();
+        const int kk = k + tid;
+        int my_v = 0, my_am = 0, my_ok = 1;
+        double my_lo = __builtin_nan("");
+        if (kk < nblk) {
+            const int m = perm[k0 + kk], p0 = kk * B;
+            double* Cb = Cbs + (size_t)kk * B * B;
+            double* vb = vbs + (size_t)kk * B;
             const int am = g.a[(long)n * N + m];
             const double sgn = am ? -1.0 : 1.0;
             bool ok = true;
@@ -108,30 +133,42 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
                 vb[i] = s / Cb[i * B + i];
                 quad += vb[i] * vb[i];
             }
-            if (!ok) atomicOr(&g.status[n], 1);
             const double dml = (am ? 0.5 * logdet : -0.5 * logdet) + 0.5 * quad + g.c0[(long)n * N + m];
             const double rho = g.rho[(long)n * N + m];
             int v;
-            double lo = __builtin_nan("");
             if (rho == 0.0 || rho == 1.0) {
                 v = 0;   // reference :298/:307: 0*log(0) = NaN reaches sample_discrete_from_log, which then returns 0
             } else {
                 const double d = dml + log(rho) - log(1.0 - rho);       // lps[1] - lps[0]
-                lo = d;
+                my_lo = d;
                 const double mx = d > 0.0 ? d : 0.0;
                 const double e0 = exp(-mx), e1 = exp(d - mx);           // exp(lps - max)
-                const double uu = g.u[(long)n * N + k0 + k];
+                const double uu = g.u[(long)n * N + k0 + kk];
                 v = (uu * (e0 + e1) > e0) ? 1 : 0;                      // cum = [e0, e0+e1]; count(r > cum)
             }
-            if (g.logodds) g.logodds[(long)n * N + k0 + k] = lo;
-            s_flip = (v != am);
-            s_sign = v ? 1 : -1;                 // forward sweep when switching on
-            s_flipped[k] = (v != am) ? (v ? 1 : -1) : 0;
-            g.a[(long)n * N + m] = v;
+            my_v = v; my_am = am; my_ok = ok;
+            if (v != am) atomicMin(&s_first, kk);
         }
+        __syncthreads();
+        const int kf = s_first;                  // first proposal of this round that flips (nblk: none)
+        if (kk < nblk && kk <= kf) {             // commit: these saw the sub-tableau the serial order shows them
+            const int m = perm[k0 + kk];
+            if (!my_ok) atomicOr(&g.status[n], 1);
+            if (g.logodds) g.logodds[(long)n * N + k0 + kk] = my_lo;
+            s_flipped[kk] = (my_v != my_am) ? (my_v ? 1 : -1) : 0;
+            g.a[(long)n * N + m] = my_v;
+            if (kk == kf) s_sign = my_v ? 1 : -1;   // forward sweep when switching on
+        }
+        if (tid == 0) s_flip = kf < nblk;
+        const int p0 = (kf < nblk ? kf : 0) * B;
+        const double* Cb = Cbs + (size_t)(kf < nblk ? kf : 0) * B * B;
+        k = kf + 1;
         __syncthreads();
         const int do_flip = s_flip, flip_sign = s_sign;   // block-uniform; re-read only after the barrier below
         __syncthreads();
+#ifdef PGL_DECIDE_TIMING
+        { const long long now = wall_clock64(); tq_eval += now - tq1; tq1 = now; ++tq_rounds; }
+#endif
         if (do_flip) {
             // Cinv = (L[p,p])^-1 = sgn * Q^-1, column x solved by thread x from the Cholesky factor
             if (tid < B) {
@@ -167,6 +204,49 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             // 8 independent loads per thread instead of one dependent load/store at a time
             // (lower triangle only, folded into a rectangle so that an element's (i, j) costs one division as before: row r of the
             // rectangle is row nl-1-r of the triangle followed by row r-1 (nl odd) or r (nl even))
+            if constexpr (BT > 0) {
+                // 4 x 4 register tiles of the lower triangle (two halves of 2 rows): the B pivot-row values of the tile's 4 columns and the
+                // B multipliers of its rows are read from LDS once per tile -- 2.5 LDS reads and no integer division per entry, where the
+                // entry-per-thread loop below spends 10 and two divisions (it was ~60 % of a flip).  Same expression per entry: same bits.
+                const int nt = (nl + 3) / 4, ntile = nt * (nt + 1) / 2;
+                for (int t = tid; t < ntile; t += nthr) {
+                    int ti = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                    while (ti * (ti + 1) / 2 > t) --ti;
+                    const int tj = t - ti * (ti + 1) / 2, i0 = ti * 4, j0 = tj * 4;
+                    double pr[BT][4];
+#pragma unroll
+                    for (int x = 0; x < BT; ++x)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) pr[x][c] = j0 + c < nl ? Prow[x * nl + j0 + c] : 0.0;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        double tm[2][BT], old_[2][4];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int i = i0 + half * 2 + r;
+#pragma unroll
+                            for (int x = 0; x < BT; ++x) tm[r][x] = i < nl ? Tm[i * BT + x] : 0.0;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) old_[r][c] = (i < nl && j0 + c <= i) ? L[i * ldl + j0 + c] : 0.0;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int i = i0 + half * 2 + r;
+                            if (i >= nl || (i >= p0 && i < p0 + BT)) continue;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int j = j0 + c;
+                                if (j > i || (j >= p0 && j < p0 + BT)) continue;
+                                double sum = 0.0;
+#pragma unroll
+                                for (int x = 0; x < BT; ++x) sum += tm[r][x] * pr[x][c];
+                                L[i * ldl + j] = old_[r][c] - sum;
+                            }
+                        }
+                    }
+                }
+            } else {
             const bool odd = nl & 1;
             const int wdt = odd ? nl : nl + 1, ntri = wdt * (odd ? (nl + 1) / 2 : nl / 2);
             for (int e0 = tid; e0 < ntri; e0 += nthr * 8) {
@@ -191,6 +271,7 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
                     L[i * ldl + j] = old_[q] - sum;
                 }
             }
+            }
             __syncthreads();
             const double sg = (flip_sign > 0) ? 1.0 : -1.0;
             for (int e = tid; e < nl * B; e += nthr) {    // pivot rows / columns
@@ -199,8 +280,14 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
                 else { const double val = sg * Tm[e]; if (i > p0 + x) L[i * ldl + p0 + x] = val; else L[(p0 + x) * ldl + i] = val; }
             }
             __syncthreads();
+#ifdef PGL_DECIDE_TIMING
+            tq_flip += wall_clock64() - tq1; ++tq_flips;
+#endif
         }
     }
+#ifdef PGL_DECIDE_TIMING
+    tq1 = wall_clock64();
+#endif
     if (tid == 0) {
         int cnt = 0;
         for (int k = 0; k < nblk; ++k)
@@ -238,6 +325,13 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             Gn[e] = v;
         }
     }
+#ifdef PGL_DECIDE_TIMING
+    __syncthreads();
+    if (tid == 0) {          // 100 MHz ticks: gather, evaluation rounds, flips, tail; counts
+        long long* dbg = reinterpret_cast<long long*>(g.Lws + (size_t)n * (KMAX + 1) * (KMAX + 1) + 200000) + 8 * window;
+        dbg[0] = tq_gather; dbg[1] = tq_eval; dbg[2] = tq_flip; dbg[3] = wall_clock64() - tq1; dbg[4] = tq_rounds; dbg[5] = tq_flips; dbg[6] = wall_clock64() - tq0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ G = (M_DD)^-1 by in-order symmetric sweeps (every pivot block is definite)
@@ -612,7 +706,7 @@ __global__ __launch_bounds__(256) void pivot_chunk_kernel(FlipArgs g, const int*
 
 size_t pgl_k_flip_lds_decide(int B, int R) {
     const int nl = R * B + 1;
-    return (2 * (size_t)nl * B + 2 * (size_t)B * B + B) * sizeof(double);
+    return (2 * (size_t)nl * B + (size_t)B * B + (size_t)R * (B * B + B)) * sizeof(double);
 }
 
 
@@ -736,9 +830,18 @@ int pgl_k_flip_decide(const PglFlipState& s, int window, hipStream_t st) {
     FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
                s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, 0, s.logodds};
     const size_t lds = pgl_k_flip_lds_decide(s.B, R);
-    static PglPerDeviceSize lds_set;                      // the request depends on (B, R): raised per device when a launch needs more
-    if (int rc = pgl_grow_dynamic_lds(reinterpret_cast<const void*>(decide_kernel), lds, lds_set)) return rc;
-    hipLaunchKernelGGL(decide_kernel, dim3(s.nb), dim3(1024), lds, st, g, window);
+    // (one LDS high-water mark for all instantiations: the request is raised on each of them whenever any launch needs more)
+#define PGL_DECIDE(b_)                                                                                                      \
+    case b_: {                                                                                                              \
+        static PglPerDeviceSize lds_set_b;                                                                                  \
+        if (int rc = pgl_grow_dynamic_lds(reinterpret_cast<const void*>(decide_kernel<b_>), lds, lds_set_b)) return rc;     \
+        hipLaunchKernelGGL(decide_kernel<b_>, dim3(s.nb), dim3(1024), lds, st, g, window);                                  \
+    } break;
+    switch (s.B <= 8 ? s.B : 0) {
+        PGL_DECIDE(0) PGL_DECIDE(1) PGL_DECIDE(2) PGL_DECIDE(3) PGL_DECIDE(4) PGL_DECIDE(5) PGL_DECIDE(6) PGL_DECIDE(7) PGL_DECIDE(8)
+        default: break;
+    }
+#undef PGL_DECIDE
     PGL_CHECK_LAUNCH();
     return PGL_OK;
 }
