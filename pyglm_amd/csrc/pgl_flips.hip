@@ -72,7 +72,9 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     double* Cinv = Prow + (size_t)nl * B;    // [B][B]
     double* Cbs = Cinv + B * B;              // [R][B][B] Cholesky factor of every proposal's block
     double* vbs = Cbs + (size_t)g.R * B * B; // [R][B]
-    __shared__ int s_flip, s_sign, s_first;
+    __shared__ int s_flip, s_sign, s_first, s_nfl;
+    __shared__ int s_fl[KMAX];              // rows of the blocks that have flipped so far (ascending)
+    if (tid == 0) s_nfl = 0;
     __shared__ int s_flipped[KMAX];
 
     const double* M = g.M + (long)n * g.strideM;
@@ -208,40 +210,51 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
                 // 4 x 4 register tiles of the lower triangle (two halves of 2 rows): the B pivot-row values of the tile's 4 columns and the
                 // B multipliers of its rows are read from LDS once per tile -- 2.5 LDS reads and no integer division per entry, where the
                 // entry-per-thread loop below spends 10 and two divisions (it was ~60 % of a flip).  Same expression per entry: same bits.
-                const int nt = (nl + 3) / 4, ntile = nt * (nt + 1) / 2;
+                // Only LIVE rows and columns are updated: those of the proposals still to come (and h), and those of the blocks that have
+                // flipped (the window's G is read from them at the end).  The rows of a block that was proposed and did not flip are never
+                // read again -- after k of 64 proposals with 15 % flips that is half the triangle.  The sub-tableau does not fit the L2 of
+                // an XCD (32 workgroups x 413 KB), so a flip is bound by the traffic to the memory-side cache: fewer bytes, not fewer flops.
+                // Compacted index a -> row: the flipped rows so far (s_fl, ascending), then the rows from the next proposal's on.
+                const int nfl = s_nfl, r_live = p0 + BT, nc = nfl + (nl - r_live);
+                auto row_of = [&](int a) { return a < nfl ? s_fl[a] : r_live + (a - nfl); };
+                const int nt = (nc + 3) / 4, ntile = nt * (nt + 1) / 2;
                 for (int t = tid; t < ntile; t += nthr) {
                     int ti = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
                     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
                     while (ti * (ti + 1) / 2 > t) --ti;
                     const int tj = t - ti * (ti + 1) / 2, i0 = ti * 4, j0 = tj * 4;
+                    int jc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) jc[c] = j0 + c < nc ? row_of(j0 + c) : -1;
                     double pr[BT][4];
 #pragma unroll
                     for (int x = 0; x < BT; ++x)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) pr[x][c] = j0 + c < nl ? Prow[x * nl + j0 + c] : 0.0;
+                        for (int c = 0; c < 4; ++c) pr[x][c] = jc[c] >= 0 ? Prow[x * nl + jc[c]] : 0.0;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         double tm[2][BT], old_[2][4];
+                        int ir[2];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
-                            const int i = i0 + half * 2 + r;
+                            const int a = i0 + half * 2 + r;
+                            ir[r] = a < nc ? row_of(a) : -1;
 #pragma unroll
-                            for (int x = 0; x < BT; ++x) tm[r][x] = i < nl ? Tm[i * BT + x] : 0.0;
+                            for (int x = 0; x < BT; ++x) tm[r][x] = ir[r] >= 0 ? Tm[ir[r] * BT + x] : 0.0;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) old_[r][c] = (i < nl && j0 + c <= i) ? L[i * ldl + j0 + c] : 0.0;
+                            for (int c = 0; c < 4; ++c) old_[r][c] = (ir[r] >= 0 && j0 + c <= a) ? L[ir[r] * ldl + jc[c]] : 0.0;
                         }
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
-                            const int i = i0 + half * 2 + r;
-                            if (i >= nl || (i >= p0 && i < p0 + BT)) continue;
+                            const int a = i0 + half * 2 + r;
+                            if (ir[r] < 0) continue;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
-                                const int j = j0 + c;
-                                if (j > i || (j >= p0 && j < p0 + BT)) continue;
+                                if (j0 + c > a) continue;
                                 double sum = 0.0;
 #pragma unroll
                                 for (int x = 0; x < BT; ++x) sum += tm[r][x] * pr[x][c];
-                                L[i * ldl + j] = old_[r][c] - sum;
+                                L[ir[r] * ldl + jc[c]] = old_[r][c] - sum;
                             }
                         }
                     }
@@ -279,7 +292,9 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
                 if (i >= p0 && i < p0 + B) { if (p0 + x <= i) L[i * ldl + p0 + x] = -Cinv[(i - p0) * B + x]; }
                 else { const double val = sg * Tm[e]; if (i > p0 + x) L[i * ldl + p0 + x] = val; else L[(p0 + x) * ldl + i] = val; }
             }
+            if (tid < B) s_fl[s_nfl + tid] = p0 + tid;      // (s_nfl was last read before the barrier above)
             __syncthreads();
+            if (tid == 0) s_nfl += B;
 #ifdef PGL_DECIDE_TIMING
             tq_flip += wall_clock64() - tq1; ++tq_flips;
 #endif
