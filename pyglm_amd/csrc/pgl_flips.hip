@@ -457,16 +457,16 @@ __global__ __launch_bounds__(256) void invert128_kernel(FlipArgs g, const double
         const double d = cp[p];
         if (tid == 0 && !(d > 0.0)) s_bad = 1;
         const double inv = 1.0 / d;
-        const double cj = cp[tc] * inv;
         const bool pivcol = tc == p;
+        // one fma and one select per element: the pivot column's thread runs the same update with cj = -inv on a zero column
+        // (0 - ci (-inv) = ci inv, and -inv in the pivot row)
+        const double cj = pivcol ? -inv : cp[tc] * inv;
 #pragma unroll
         for (int r = 0; r < kk / 2; ++r) {
             const int i = tr + 2 * r;
             const double ci = cp[i];
-            double v;
-            if (pivcol) v = (i == p) ? -inv : ci * inv;
-            else v = (i == p) ? cj : a[r] - ci * cj;
-            a[r] = v;
+            const double v = (pivcol ? 0.0 : a[r]) - ci * cj;
+            a[r] = (i == p) ? cj : v;
         }
         if (tc == p + 1) {                    // the next pivot column, already updated
 #pragma unroll

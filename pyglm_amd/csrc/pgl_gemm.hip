@@ -817,7 +817,10 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
             if (variant == 3 && ntm * (ntm + 1) / 2 * a.nbatch < 2L * n_cu) return launch_gram_fine(a, st);
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
-        case PGL_GEMM_PLAIN: PGL_CHECK_ARG(a.tri == 0); return launch<2, 4, 1, false>(a, st);
+        case PGL_GEMM_PLAIN:
+            PGL_CHECK_ARG(a.tri == 0);
+            if (a.N <= 128) return launch<2, 2, 1, false>(a, st);     // (the 128 x 128 blocks of the pivot-block inversion: no half-empty 256-wide tile)
+            return launch<2, 4, 1, false>(a, st);
         case PGL_GEMM_SQUARES:
             PGL_CHECK_ARG(a.tri == 0 && !a.pipe);
             if (a.M <= 64) return launch<1, 4, 1, false, 2, false, true>(a, st);      // few neurons per batch (BASELINE configs[4]: 4): 64-row tiles
