@@ -63,6 +63,7 @@ struct PglGemmArgs {
     int* sched;                                // persistent launch: 8 per-XCD work counters, zeroed before the launch
     const int* batch_dim; int dim_off;         // optional per-batch size d = max(0, batch_dim[b] - dim_off)
     int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed;  3: M = min(g.M, d), N = d
+    const int* batch_row_off;                  // optional: batch b reads B and writes C from row batch_row_off[b] on (panels stacked per neuron; not for the TRI kinds' skinny rows)
     int pipe;                                  // 1: a rank-k product of the flips / the Cholesky: may take the update pipeline (pgl_update.hip) where that is faster; 2: must
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2, PGL_GEMM_SQUARES = 3 };   // SQUARES: PLAIN on the squared elements of A and B
@@ -117,6 +118,7 @@ int pgl_k_i8_gram(const int8_t*, long, int, const int8_t*, int8_t*, int8_t*, int
 long pgl_k_i8_kp(int);
 int pgl_k_i8_crt(const int8_t*, const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);
 int pgl_k_flip_apply(const PglFlipState&, int, int, int, hipStream_t);
+int pgl_k_flip_apply_pair(const PglFlipState&, int phase, int window, int* ws, hipStream_t);
 int pgl_k_flip_permute(const PglFlipState&, const double*, long, long, hipStream_t);
 int pgl_k_flip_decide(const PglFlipState&, int, hipStream_t);
 int pgl_k_flip_pivot_list(const PglFlipState&, int*, long, int*, hipStream_t);

@@ -50,6 +50,7 @@ struct FlipArgs {
     int permuted;                                // 1: tableau rows/columns are in VISIT order (position k holds block perm[k]; bias, h last)
     int c_begin;                                 // first column the pivot-row gather has to produce (trailing-only window updates)
     double* logodds;                             // [nb][N] or null: lps[1] - lps[0] per proposal step (parity checks)
+    const int* row_off;                          // [nb] or null: the gathered pivot rows go to Ut rows row_off[n].. (second panel of a window pair)
 };
 
 __device__ __forceinline__ double tab_get(const double* M, long ld, int i, int j) { return i >= j ? M[(long)i * ld + j] : M[(long)j * ld + i]; }
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void gather_panel_kernel(FlipArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* M = g.M + (long)n * g.strideM;
     const int* idx = g.d_idx + (long)n * KMAX;
-    double* Ut = g.Ut + (long)n * KMAX * g.ldu;
+    double* Ut = g.Ut + (long)n * KMAX * g.ldu + (g.row_off ? (long)g.row_off[n] * g.ldu : 0);
     __shared__ int s_idx[GT];
     __shared__ int s_min;
     __shared__ double tile[GT][GT + 1];
@@ -823,6 +824,71 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
         PGL_CHECK_LAUNCH();
     }
     return PGL_OK;
+}
+
+// ---- two proposal windows per pass over the trailing tableau (visit-order tableau)
+// The update after a window is bound by the read-modify-write of the trailing tableau (rank ~50 at the chain's flip rates), so the panels of
+// windows w and w + 1 are STACKED and applied in one pass: after window w only the column strip of window w + 1 is brought up to date (a
+// skinny product: that is all the proposals of w + 1 and the gather of their pivot rows read), the pivot rows of w + 1 go behind those of w in
+// the panel buffers (per-neuron row offset = the first panel's padded length), and one product of rank k_w + k_{w+1} updates the rest.  Every
+// entry sees the same multiply-adds in the same order as with one pass per window: same bits.  A neuron whose first panel would not leave
+// room for a full second one (k_w > KMAX - window rows) takes the ordinary pass after window w (its batch_k is zero in the pair's products).
+// ws: 4 x nb ints of scratch (off, kfull, kstrip, kcomb).
+__global__ __launch_bounds__(256) void pair_plan_first_kernel(const int* __restrict__ batch_k, int nb, int room, int* __restrict__ ws) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= nb) return;
+    const int k1 = batch_k[n];
+    const bool paired = k1 + room <= KMAX;
+    ws[n] = paired ? k1 : 0;                 // row offset of the second panel
+    ws[nb + n] = paired ? 0 : k1;            // rank of the ordinary pass (unpaired neurons)
+    ws[2 * nb + n] = paired ? k1 : 0;        // rank of the strip update
+}
+__global__ __launch_bounds__(256) void pair_plan_second_kernel(const int* __restrict__ batch_k, int nb, int* __restrict__ ws) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < nb) ws[3 * nb + n] = ws[n] + batch_k[n];
+}
+
+int pgl_k_flip_apply_pair(const PglFlipState& s, int phase, int window, int* ws, hipStream_t st) {
+    const int R_ = pgl_k_flip_window_blocks(s.B);
+    const int Md = s.N * s.B + 2;
+    if (!s.permuted || (long)(window + 1) * R_ >= s.N) return PGL_OK;          // last window: nothing is read afterwards
+    const int r0 = ((window + 1) * R_ * s.B) & ~1;                                // first live row / column after `window`
+    FlipArgs g{s.M, s.ldj, s.strideM, s.N, s.B, R_, s.perm, s.u, s.rho, s.c0, s.a, s.skip, s.d_idx, s.d_sign, s.d_cnt,
+               s.batch_k, s.G, s.Lws, s.Ut, s.Wt, s.ldu, s.status, s.permuted, r0, s.logodds, phase ? ws : nullptr};
+    hipLaunchKernelGGL(gather_panel_kernel, dim3((unsigned)((s.ldu - r0 + GT - 1) / GT), KMAX / GT, s.nb), dim3(256), 0, st, g);
+    PGL_CHECK_LAUNCH();
+    const int ncol = (int)s.ldu - r0;
+    PglGemmArgs w{};
+    w.A = s.G; w.lda = KMAX; w.strideA = (long)KMAX * KMAX;
+    w.B = s.Ut + r0; w.ldb = s.ldu; w.strideB = (long)KMAX * s.ldu;
+    w.C = s.Wt + r0; w.ldc = s.ldu; w.strideC = (long)KMAX * s.ldu;
+    w.M = KMAX; w.N = ncol; w.K = KMAX; w.a_cols = KMAX; w.b_cols = ncol; w.nbatch = s.nb;
+    w.alpha = 1.0; w.beta = 0.0; w.tri = 0; w.batch_k = s.batch_k; w.batch_dim = s.batch_k; w.dim_off = 0; w.dim_mode = 2;
+    w.batch_row_off = phase ? ws : nullptr;
+    w.pipe = 1;
+    if (int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st)) return rc;
+    PglGemmArgs t{};
+    t.A = s.Wt + r0; t.lda = s.ldu; t.strideA = (long)KMAX * s.ldu;
+    t.B = s.Ut + r0; t.ldb = s.ldu; t.strideB = (long)KMAX * s.ldu;
+    t.C = s.M + (long)r0 * s.ldj + r0; t.ldc = s.ldj; t.strideC = s.strideM;
+    t.M = Md - r0; t.N = Md - r0; t.K = KMAX; t.a_cols = ncol; t.b_cols = ncol; t.nbatch = s.nb;
+    t.alpha = -1.0; t.beta = 1.0; t.tri = 1; t.pipe = 1;
+    if (phase == 0) {
+        const int room = (R_ * s.B + 15) & ~15;
+        hipLaunchKernelGGL(pair_plan_first_kernel, dim3((s.nb + 255) / 256), dim3(256), 0, st, s.batch_k, s.nb, room, ws);
+        PGL_CHECK_LAUNCH();
+        t.batch_k = ws + s.nb;                        // the ordinary pass, for the neurons that cannot pair
+        if (int rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st)) return rc;
+        // the column strip of window + 1 (its rows down to the last): all that window's proposals and pivot-row gather read
+        const int nblk1 = min(R_, s.N - (window + 1) * R_);
+        PglGemmArgs q = t;
+        q.N = (window + 1) * R_ * s.B + nblk1 * s.B - r0; q.tri = 0; q.pipe = 0; q.batch_k = ws + 2 * s.nb;
+        return pgl_launch_gemm(PGL_GEMM_PLAIN, q, st);
+    }
+    hipLaunchKernelGGL(pair_plan_second_kernel, dim3((s.nb + 255) / 256), dim3(256), 0, st, s.batch_k, s.nb, ws);
+    PGL_CHECK_LAUNCH();
+    t.batch_k = ws + 3 * s.nb;                        // both panels, stacked
+    return pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
 }
 
 int pgl_k_flip_permute(const PglFlipState& s, const double* J, long ldjs, long strideJ, hipStream_t st) {

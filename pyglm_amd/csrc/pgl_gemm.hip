@@ -102,7 +102,8 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
     const double* __restrict__ Ab = g.A + (long)batch * g.strideA;
-    const double* __restrict__ Bb = g.B + (long)batch * g.strideB;
+    const long roff_ = g.batch_row_off ? (long)g.batch_row_off[batch] : 0;     // rows of B and C this batch starts at
+    const double* __restrict__ Bb = g.B + (long)batch * g.strideB + roff_ * g.ldb;
     const int zg = batch * WZ + wz;                   // weight column / output index of this wave
     const bool zvalid = !WEIGHTED || zg < g.nz_total;
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
     const int frow = lane >> 4, fcol = lane & 15;
     const bool interior = CINIT && m0 + C::BM <= Mv && n0 + C::BN <= Nv;     // workgroup-uniform: no bounds checks inside the tile
     if constexpr (CINIT) {
-        const double* __restrict__ cp = g.C + (long)batch * g.strideC + (long)(m0 + wm * 64 + frow) * g.ldc + (n0 + wn * 64 + fcol);
+        const double* __restrict__ cp = g.C + (long)batch * g.strideC + roff_ * g.ldc + (long)(m0 + wm * 64 + frow) * g.ldc + (n0 + wn * 64 + fcol);
         if (interior) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -421,7 +422,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
 
     // ---- epilogue.  f64 C/D fragment: row = (lane>>4) + 4*reg, col = lane&15 (verified on hardware)
     if (!zvalid) return;
-    double* __restrict__ Cb = g.C + (WEIGHTED ? (long)zg : (long)batch) * g.strideC;
+    double* __restrict__ Cb = g.C + (WEIGHTED ? (long)zg : (long)batch) * g.strideC + roff_ * g.ldc;
     const double alpha = g.alpha, beta = g.beta;
     // accumulator tile (i, j) of acc[4][4] -> offsets inside the workgroup tile: 64 x 64 wave tiles, or (wide Gram layout)
     // tile f = 4 i + j of a 32 x 128 wave tile

@@ -371,12 +371,17 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 clk.toc(m);
             }
             const int nwin = (N + R - 1) / R;
+            // windows in pairs: one pass over the trailing tableau for two windows' panels (pgl_k_flip_apply_pair); its four counters per
+            // neuron live in the pivot-list buffer, which is free between the initial sweep and the weight draw
+            static const bool pair_env = [] { const char* e = getenv("PGL_FLIP_PAIR"); return !(e && e[0] == '0'); }();     // A/B switch
+            const bool pair = pair_env && s->visit_order;
             for (int w = 0; w < nwin; ++w) {
                 auto m = clk.tic(ST_FDEC);
                 RC(pgl_k_flip_decide(fs, w, st));
                 clk.toc(m);
                 m = clk.tic(ST_FAPP);
-                RC(pgl_k_flip_apply(fs, 1, 0, w, st));
+                if (!pair || (w % 2 == 0 && w + 1 >= nwin)) RC(pgl_k_flip_apply(fs, 1, 0, w, st));
+                else RC(pgl_k_flip_apply_pair(fs, w % 2, w, s->act, st));
                 clk.toc(m);
             }
         }

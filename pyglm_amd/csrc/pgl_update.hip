@@ -120,8 +120,9 @@ __device__ __forceinline__ void upd_item(const UpdArgs& u, const int batch, cons
     // upper (tri 2): columns of half wz = 0 end before the rows begin, same condition
     const bool idle = g.tri != 0 && mnr == 2 * maj + 1 && wz == 0;
 
+    const long roff_ = g.batch_row_off ? (long)g.batch_row_off[batch] : 0;     // rows of B and C this batch starts at
     const double* __restrict__ Ab = g.A + (long)batch * g.strideA;
-    const double* __restrict__ Bb = g.B + (long)batch * g.strideB;
+    const double* __restrict__ Bb = g.B + (long)batch * g.strideB + roff_ * g.ldb;
 
     // ---- DMA pieces: a K tile is 16 rows of (BM + BN) / 128 = 3 segments of 128 doubles; wave w moves rows w and w + 8: 6 requests.
     // Every request keeps a per-lane global cursor that moves down one K tile after use, and a wave-uniform LDS offset inside a stage.
@@ -185,7 +186,7 @@ __device__ __forceinline__ void upd_item(const UpdArgs& u, const int batch, cons
     // ---- accumulators: tile f = 8 i + j (i < 2 row blocks, j < 8 column blocks of 16) in acc[f >> 2][f & 3];
     // f64 C/D fragment: row = (lane >> 4) + 4 reg, col = lane & 15
     d4_t acc[4][4];
-    double* __restrict__ Cb = g.C + (long)batch * g.strideC + (long)(m0 + rloc + frow) * g.ldc + (n0 + cloc + fcol);
+    double* __restrict__ Cb = g.C + (long)batch * g.strideC + roff_ * g.ldc + (long)(m0 + rloc + frow) * g.ldc + (n0 + cloc + fcol);
     const bool interior = m0 + C::BM <= Mv && n0 + C::BN <= Nv;
     const bool neg = g.alpha < 0.0;
     if (u.cinit) {
