@@ -302,7 +302,9 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     // super-panels of SP 64-row sub-panels: before sub-panel i is factored its 64-row strip takes the updates of sub-panels 0..i-1 (one
     // rank-64i strip update), and the trailing matrix is updated ONCE per super-panel with rank 64 SP.  The trailing passes stream the
     // whole remaining matrix (HBM-bound at rank 128): SP = 4 halves them again, SP = 6 is the measured optimum.
-    static const int SP = [] { const char* e = getenv("PGL_CHOL_SP"); const int v = e ? atoi(e) : 6; return v >= 1 && v <= 8 ? v : 6; }();      // A/B switch (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274)
+    // A/B switch PGL_CHOL_SP (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274; 32 769-dim systems x 4, ms per 8: 6: 1887, 8: 1862)
+    static const int SP_env = [] { const char* e = getenv("PGL_CHOL_SP"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
+    const int SP = SP_env ? SP_env : (na_max > 8192 ? 8 : 6);
     bool done = false;
     for (int q0 = 0; q0 < na_max && !done; q0 += SP * NBC) {
         for (int i = 0; i < SP; ++i) {
