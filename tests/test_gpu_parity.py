@@ -619,3 +619,51 @@ def test_prefix_run_equals_the_same_neurons_of_a_full_sweep(torch_dev, gram):
             np.testing.assert_array_equal(x[:k], y[:k])
             np.testing.assert_array_equal(x[k:], x0[k:])
         np.testing.assert_array_equal(part[3][:k], full[3][:k])
+
+
+_PAIR_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+N, B, T = 200, 5, 1500
+D = N * B
+rng = np.random.default_rng(4)
+Y = (rng.random((T, N)) < 0.1).astype(float)
+X = rng.random((T, N, B)) * (rng.random((T, N, B)) < 0.3) * 0.3
+a = rng.random((N, N)) < 0.5
+W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
+b = np.full(N, -2.0)
+out = {}
+for tag, S in (("few", 4.0), ("many", 0.02)):          # a loose slab: few flips per window; a tight one: most blocks flip (first panels too long to pair)
+    hyp = prior_terms(np.tile(np.eye(B) * S, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+    eng = GibbsEngine(N, B, gram="fp64", batch=64)
+    eng.keep_logodds = True
+    eng.add_data(Y, X=X)
+    perm, u, z = make_draws(9, 0, range(N), N, D)
+    a1, W1, b1, ll = eng.sweep(a, W, b, np.full((N, N), 0.5), *hyp, perm, u, z, seed=9, sweep=0)
+    out.update({tag + "_a": a1, tag + "_W": W1, tag + "_b": b1, tag + "_lo": eng.logodds.cpu().numpy()})
+    del eng
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev, tmp_path):
+    """pgl_k_flip_apply_pair stacks the panels of two proposal windows and passes over the trailing tableau once: every entry must see the same
+    multiply-adds in the same order as with a pass per window (PGL_FLIP_PAIR=0, a switch read once per process: two child processes).
+    N = 200: four windows (64, 64, 64, 8 blocks), one batch ragged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for v in ("1", "0"):
+        out = str(tmp_path / ("pair%s.npz" % v))
+        env = dict(os.environ, PGL_FLIP_PAIR=v)
+        p = subprocess.run([sys.executable, "-c", _PAIR_SCRIPT, root, out], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(dict(np.load(out)))
+    assert set(res[0]) == set(res[1])
+    for k in res[0]:
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+    flips_few = (res[0]["few_a"] != res[0]["many_a"]).sum()
+    assert flips_few > 0            # (the two regimes are different chains)
