@@ -340,6 +340,19 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
     I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
     I8_MIN_D, I8_MIN_T = 1024, 2048
+    I8_SMALL_D, I8_SMALL_T = 640, 16384      # between 640 and 1024 columns: only where the 320-tile padding leaves a gain (_i8_pays)
+
+    def _i8_pays(self, T, planes=13):
+        """gram='auto' below I8_MIN_D: the integer path only if a cost model says it wins by 10 %.  Per neuron and time bin, from the rates
+        measured on MI355X: fp64 kernel 2.9e-14 s per multiply-add slot of its lower 128-tiles; integer products
+        1.12e-15 s per slot and plane of the lower 320-tiles at these small item counts, plane conversion 1.9e-13 s per byte.  D = 640
+        (two tiles exactly: measured 40 against 46 ms at BASELINE configs[1]) and D = 960 pass; D = 650 (padded to 960 rows) does not."""
+        if self.D < self.I8_SMALL_D or T < self.I8_SMALL_T:
+            return False
+        nt, nq = -(-self.D // 128), -(-self.D // 320)
+        t64 = nt * (nt + 1) // 2 * 128 * 128 * 2.9e-14
+        t8 = planes * (nq * (nq + 1) // 2 * 320 * 320 * 1.12e-15 + nq * 320 * 1.9e-13)
+        return t8 < 0.9 * t64
 
     def _i8_plan(self, T):
         """-> None (this data set's Gram runs on the fp64 kernel) or how it goes through the int8 MFMA: dict(planes, resident, G, slice).
@@ -351,7 +364,7 @@ class GibbsEngine(object):
         import os
         if self.obs == 2 or self.design_only or self.likelihood_only or self.gram == "fp64":
             return None
-        if self.gram != "int8" and (self.D < self.I8_MIN_D or T < self.I8_MIN_T):
+        if self.gram != "int8" and (T < self.I8_MIN_T or (self.D < self.I8_MIN_D and not self._i8_pays(T))):
             return None
         lib = _lib.load()
         planes = self.planes or lib.pgl_i8_min_planes(T)

@@ -34,7 +34,8 @@ def test_self_launch_two_ranks_equals_one_rank():
         assert abs(d["value"] - 2 / (d["ms_per_step"] * 2e-3)) < 1e-9 * d["value"]
         assert len(d["per_rank"]) == n and sorted(r["rank"] for r in d["per_rank"]) == list(range(n))
         assert sum(r["neurons"] for r in d["per_rank"]) == 128
-        assert d["roofline"]["achieved"] > 0 and d["roofline"]["unit"] == "TFLOP/s"
+        # (this size goes through the integer Gram since gram="auto" compares the two paths' tile areas below 1024 columns: TOP/s)
+        assert d["roofline"]["achieved"] > 0 and d["roofline"]["unit"] in ("TFLOP/s", "TOP/s")
     assert two["per_rank"][0]["collectives_ms_per_step"] > 0
     # the chain does not depend on the number of ranks (random inputs are keyed by the global neuron); the log-likelihood is a sum of
     # per-rank partial sums (one all_reduce), so it agrees to rounding of the summation order, not to the bit

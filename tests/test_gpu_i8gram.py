@@ -442,7 +442,9 @@ def test_auto_takes_the_integer_gram_where_it_pays():
     from pyglm_amd.engine import GibbsEngine
     rng = np.random.default_rng(0)
     for N, B, T, obs, want in [(210, 5, 2100, "bernoulli", True), (210, 5, 1500, "bernoulli", False), (60, 3, 4000, "bernoulli", False),
-                               (210, 5, 2100, "gaussian", False)]:
+                               (210, 5, 2100, "gaussian", False),
+                               # between 640 and 1024 columns: where the 320-tile padding leaves a gain (GibbsEngine._i8_pays)
+                               (128, 5, 17000, "bernoulli", True), (130, 5, 17000, "bernoulli", False), (128, 5, 9000, "bernoulli", False)]:
         eng = GibbsEngine(N, B, n1=4, obs=obs, batch=4)
         ds = eng.add_data((rng.random((T, N)) < 0.1).astype(float), X=rng.random((T, N, B)) * 0.1)
         assert eng.gram == "auto" and ds.int8 == want, (N, B, T, obs)
