@@ -488,9 +488,10 @@ def test_edge_shapes_vs_oracle(torch_dev, N, B, T, rho):
         assert not a1.any() and np.all(W1 == 0)
 
 
-def test_three_datasets_accumulate(torch_dev):
+@pytest.mark.parametrize("gram", ["auto", "int8"])
+def test_three_datasets_accumulate(torch_dev, gram):
     """data_list may hold several datasets whose sufficient statistics add (regression.py:237-260); the PG element index
-    continues across datasets"""
+    continues across datasets.  int8: every data set's product goes through its own planes, scales (batch norms) and CRT, the CRTs adding up in J"""
     from pyglm_amd.engine import make_draws
     rng = np.random.default_rng(9)
     N, B = 6, 2
@@ -501,9 +502,10 @@ def test_three_datasets_accumulate(torch_dev):
     a = rng.random((N, N)) < 0.5
     W = rng.standard_normal((N, N, B)) * 0.5 * a[:, :, None]
     b = rng.standard_normal(N) * 0.3
-    eng = _engine(N, B)
+    eng = _engine(N, B, gram=gram)
     for X, Y in zip(Xs, Ys):
-        eng.add_data(Y, X=X)
+        ds = eng.add_data(Y, X=X)
+        assert ds.int8 == (gram == "int8")
     regs = [orc.Regression(N, B, **kw) for _ in range(N)]
     hyp = _hyp(regs)
     perm, u, z = make_draws(5, 3, range(N), N, N * B)
