@@ -466,3 +466,22 @@ def test_shard_override_sweeps_its_rows_only():
         np.testing.assert_array_equal(part.weights[lo:hi], W0[lo:hi])
         np.testing.assert_array_equal(part.biases[lo:hi], b0[lo:hi])
     assert np.isfinite(part.log_likelihood())
+
+
+def test_integer_gram_gate_between_640_and_1024_columns():
+    """gram='auto' below 1024 columns takes the integer path only where the 320-tile padding leaves a modelled gain of 10 %
+    (GibbsEngine._i8_pays; pure arithmetic, no GPU): two or three exact tiles yes, a column more than a multiple of 320 no"""
+    from pyglm_amd.engine import GibbsEngine
+
+    class Shape(object):
+        I8_SMALL_D, I8_SMALL_T = GibbsEngine.I8_SMALL_D, GibbsEngine.I8_SMALL_T
+
+    def pays(D, T):
+        s = Shape()
+        s.D = D
+        return GibbsEngine._i8_pays(s, T)
+
+    assert pays(640, 50000) and pays(960, 50000) and pays(640, 16384)
+    assert not pays(650, 50000) and not pays(700, 50000) and not pays(1000, 50000)       # padded to 960 / 1280 rows
+    assert not pays(639, 50000) and not pays(320, 50000) and not pays(180, 10 ** 6)      # below the floor
+    assert not pays(640, 16383)                                                           # short data sets keep the fp64 kernel
