@@ -331,7 +331,8 @@ def main():
 
     watch = PowerWatch() if rank == 0 else None
 
-    timed_stages = TIMED_STAGES if N >= 64 else TIMED_STAGES_SMALL
+    # (sweeps of a second or more: ~550 event pairs are noise; configs[0] / configs[1] -- 3 / 50 ms per sweep -- keep the dominant kernel's only)
+    timed_stages = TIMED_STAGES if float(N) * N * B * T >= 1e11 else TIMED_STAGES_SMALL
 
     def timed(steps, profile=timed_stages, watched=False):
         """`steps` sweeps bracketed by barrier + synchronize on both sides -> (max-over-ranks seconds, this rank's seconds, stage table,
