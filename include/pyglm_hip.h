@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 7
+#define PGL_ABI_VERSION 8
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -34,8 +34,8 @@ const char* pgl_last_error(void);
 /* out[4*i..4*i+3] = Philox4x32-10(counter = (j | purpose<<24, elem0+i, stream lo, stream hi), key = seed). Test hook. */
 int pgl_philox_words(uint64_t seed, uint32_t purpose, uint32_t j, uint64_t elem0, uint64_t stream, uint32_t* out, size_t n, void* hip_stream);
 
-/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; any real b >= 0: floor(b) <= 12 Devroye draws of PG(1, z) plus the sum-of-gammas series for
- * the fractional part, the series alone for b > 12 -- pgl_rng.h).
+/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; any real b >= 0: floor(b) <= 64 exact Devroye draws of PG(1, z) plus the sum-of-gammas series for
+ * the fractional part only; the series alone for b > 64 -- pgl_rng.h).
  * Replaces pypolyagamma.pgdrawvpar(ppgs, n, z, out) at pyglm/regression.py:504-507 (samplers built at :474-477). */
 int pgl_pg_draw(const double* b, const double* z, double* out, size_t len, uint64_t seed, uint64_t stream, uint64_t elem0, void* hip_stream);
 
@@ -224,6 +224,7 @@ typedef struct {
                                     * pgl_sweep_t.i8_norm the scales of omega_n X are taken for a whole batch of neurons at once (see there) */
 } pgl_dataset_t;
 
+#define PGL_I8_MAX_GROUP 64
 #define PGL_NSTAGES 16
 typedef struct {                   /* host; zero-initialise.  Per stage (pgl_stage_name): HIP-event time on the launch stream, calls, work */
     double ms[PGL_NSTAGES];
@@ -238,7 +239,8 @@ typedef struct {
     int N, B, n0, nloc, nb;        /* neurons, basis functions, first local neuron (global index), local neurons, neurons per batch */
     int obs; double xi;            /* 0 Bernoulli, 1 negative binomial (b = y + xi), 2 Gaussian */
     int visit_order;               /* 1: sweep tableau in proposal order (see pgl_flip_t) */
-    int planes, i8_group;          /* integer Gram: moduli in use where a data set does not say, neurons per launch (<= 8) */
+    int planes, i8_group;          /* integer Gram: moduli in use where a data set does not say, neurons per launch (<= PGL_I8_MAX_GROUP; 8 at large D,
+                                    * more where a plane has only a few tiles: multiples of 8 fill the per-XCD work lists) */
     const pgl_dataset_t* datasets; int ndatasets;      /* host array */
     int* a; double* W; double* b;  /* chain state, in/out: [nloc][N] (0/1), [nloc][D] (zeros where a = 0), [nloc] */
     const double* rho;             /* [nloc][N] */
@@ -280,6 +282,8 @@ typedef struct {
     int all_deterministic;         /* 1: the caller knows every row has rho in {0, 1} (regression.py:153-155): the flip stage is not launched */
     int init_rows_bound;           /* upper bound of 1 + B * (active blocks of any local neuron) BEFORE the sweep */
     int active_rows_bound;         /* upper bound of the same AFTER the flips (only known when all_deterministic) */
+    int flip_single_pass;          /* 1: one pass over the trailing tableau per proposal window instead of one per pair of windows -- the same
+                                    * multiply-adds in the same order, the same bits (tests/test_gpu_parity.py compares the two) */
     pgl_stage_times_t* times;      /* optional (host): stage timing */
 } pgl_sweep_t;
 

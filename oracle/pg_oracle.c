@@ -181,7 +181,7 @@ static double pg_draw_one(double z, pg_rng* r) {
  * PG(b, z) = floor(b) draws of PG(1, z) + PG(frac(b), z) by infinite divisibility; for b > PG_DEVROYE_MAX the whole shape goes through
  * the series (cost independent of b). */
 #define PG_SERIES_TERMS 32
-#define PG_DEVROYE_MAX 12
+#define PG_DEVROYE_MAX 64
 
 static double rng_gamma(double alpha, pg_rng* r) {
     double boost = 1.0;

@@ -13,7 +13,6 @@
 // spreads over as many workgroups as it has rows / 256, and U streams through once.  (One workgroup per neuron doing all of it took
 // 34 ms per batch at cfg3 and over a second per batch at the 32 769-dim systems of configs[4].)
 #include "pgl_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -302,8 +301,8 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     // super-panels of SP 64-row sub-panels: before sub-panel i is factored its 64-row strip takes the updates of sub-panels 0..i-1 (one
     // rank-64i strip update), and the trailing matrix is updated ONCE per super-panel with rank 64 SP.  The trailing passes stream the
     // whole remaining matrix (HBM-bound at rank 128): SP = 4 halves them again, SP = 6 is the measured optimum.
-    // A/B switch PGL_CHOL_SP (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274; 32 769-dim systems x 4, ms per 8: 6: 1887, 8: 1862)
-    static const int SP_env = [] { const char* e = getenv("PGL_CHOL_SP"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
+    // (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274; 32 769-dim systems x 4, ms per 8: 6: 1887, 8: 1862)
+    static const int SP_env = [] { const int v = pgl_ab_int("PGL_CHOL_SP", 0); return v >= 1 && v <= 8 ? v : 0; }();
     const int SP = SP_env ? SP_env : (na_max > 8192 ? 8 : 6);
     bool done = false;
     for (int q0 = 0; q0 < na_max && !done; q0 += SP * NBC) {

@@ -11,6 +11,15 @@
 
 void pgl_set_error(const char* fmt, ...);
 
+// Tuning knobs for same-box A/B runs exist only in a -DPGL_AB build (`make ab` -> lib/libpyglm_hip_ab.so, never loaded by the package):
+// the shipped library reads no environment variable.
+#ifdef PGL_AB
+#include <cstdlib>
+inline int pgl_ab_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int pgl_ab_int(const char*, int dflt) { return dflt; }
+#endif
+
 // Library state is kept PER DEVICE (a process may drive several GPUs, one engine each): the dynamic-LDS attribute of a kernel belongs to the
 // device it was set on, and so do the CU count and the scheduler scratch of the persistent launches.
 constexpr int PGL_MAX_DEVICES = 32;

@@ -20,7 +20,6 @@
 // (the non-pivot formula is the same for forward and reverse sweeps; derivation in DESIGN.md).  The rank-k update
 // runs on the fp64 MFMA kernel (pgl_gemm.hip, lower-triangular tiles only).
 #include "pgl_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -80,9 +79,6 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
 
     const double* M = g.M + (long)n * g.strideM;
     const int* perm = g.perm + (long)n * N;
-#ifdef PGL_DECIDE_TIMING
-    long long tq0 = wall_clock64(), tq_eval = 0, tq_flip = 0, tq_gather = 0, tq_rounds = 0, tq_flips = 0, tq1;
-#endif
     // the window's sub-tableau is symmetric: only its lower triangle (i >= j) is kept and updated -- half the read-modify-writes per flip
     for (int e = tid; e < nl * nl; e += nthr) {
         const int i = e / nl, j = e % nl;
@@ -101,13 +97,7 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
     // applied by the whole workgroup, and the rest is evaluated again.  A window costs (flips + 1) evaluation rounds instead of one
     // serial evaluation per proposal (64 of them, a dozen dependent L2 reads each); the decisions are the same function of the same numbers.
     int k = 0;
-#ifdef PGL_DECIDE_TIMING
-    tq_gather = wall_clock64() - tq0;
-#endif
     while (k < nblk) {
-#ifdef PGL_DECIDE_TIMING
-        tq1 = wall_clock64();
-#endif
         if (tid == 0) s_first = nblk;
         __syncthreads();
         const int kk = k + tid;
@@ -169,9 +159,6 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
         __syncthreads();
         const int do_flip = s_flip, flip_sign = s_sign;   // block-uniform; re-read only after the barrier below
         __syncthreads();
-#ifdef PGL_DECIDE_TIMING
-        { const long long now = wall_clock64(); tq_eval += now - tq1; tq1 = now; ++tq_rounds; }
-#endif
         if (do_flip) {
             // Cinv = (L[p,p])^-1 = sgn * Q^-1, column x solved by thread x from the Cholesky factor
             if (tid < B) {
@@ -296,14 +283,8 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             if (tid < B) s_fl[s_nfl + tid] = p0 + tid;      // (s_nfl was last read before the barrier above)
             __syncthreads();
             if (tid == 0) s_nfl += B;
-#ifdef PGL_DECIDE_TIMING
-            tq_flip += wall_clock64() - tq1; ++tq_flips;
-#endif
         }
     }
-#ifdef PGL_DECIDE_TIMING
-    tq1 = wall_clock64();
-#endif
     if (tid == 0) {
         int cnt = 0;
         for (int k = 0; k < nblk; ++k)
@@ -341,13 +322,6 @@ __global__ __launch_bounds__(1024) void decide_kernel(FlipArgs g, int window) {
             Gn[e] = v;
         }
     }
-#ifdef PGL_DECIDE_TIMING
-    __syncthreads();
-    if (tid == 0) {          // 100 MHz ticks: gather, evaluation rounds, flips, tail; counts
-        long long* dbg = reinterpret_cast<long long*>(g.Lws + (size_t)n * (KMAX + 1) * (KMAX + 1) + 200000) + 8 * window;
-        dbg[0] = tq_gather; dbg[1] = tq_eval; dbg[2] = tq_flip; dbg[3] = wall_clock64() - tq1; dbg[4] = tq_rounds; dbg[5] = tq_flips; dbg[6] = wall_clock64() - tq0;
-    }
-#endif
 }
 
 // ------------------------------------------------------------------ G = (M_DD)^-1 by in-order symmetric sweeps (every pivot block is definite)
@@ -727,7 +701,7 @@ size_t pgl_k_flip_lds_decide(int B, int R) {
 
 
 int pgl_k_flip_window_blocks(int B) {
-    static const int kwin = [] { const char* e = getenv("PGL_FLIP_WINDOW"); const int v = e ? atoi(e) : KWIN; return v >= 16 && v <= KMAX - 2 ? v : KWIN; }();   // A/B switch
+    static const int kwin = [] { const int v = pgl_ab_int("PGL_FLIP_WINDOW", KWIN); return v >= 16 && v <= KMAX - 2 ? v : KWIN; }();
     int r = kwin / B;                                   // blocks per window: at most KMAX pivots ...
     while (r > 1 && pgl_k_flip_lds_decide(B, r) > 150 * 1024) --r;   // ... and the LDS scratch of decide_kernel must fit
     return r < 1 ? 0 : r;

@@ -22,8 +22,6 @@
 //     one XCD share the same X panels through that XCD's L2; the Gram is launched persistently (one workgroup per CU
 //     pulling XCD-local items) because the dispatcher's round-robin drifts over long launches.
 #include "pgl_common.h"
-#include <cstdlib>
-
 
 namespace {
 
@@ -800,22 +798,18 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
         // Measured at cfg3 (tools/ubench_update.hip, same bits on both kernels): the write-only form (beta = 0: W = G U) is 8-23 % faster
         // there; the read-modify-write forms are not (one persistent workgroup per CU cannot hide a tile's 512 KiB of C traffic behind
         // another workgroup's MFMAs: 62.0 vs 62.2 TFLOP/s at rank 512, 0.77x at rank 64) and stay on the generic kernel.
-        // PGL_UPDATE_PIPE=0: never; =all: every supported product (A/B switch).
-        static const int mode = [] { const char* e = getenv("PGL_UPDATE_PIPE"); return !e ? 1 : e[0] == '0' ? 0 : e[0] == 'a' ? 2 : 1; }();
-        if (mode && (mode == 2 || a.pipe == 2 || a.beta == 0.0) && pgl_update_supported(a)) return pgl_launch_update(a, st);
+        // (pipe = 2, the C ABI's `kernel` argument, forces the pipeline: tests/test_gpu_update.py compares the two kernels bit for bit)
+        if ((a.pipe == 2 || a.beta == 0.0) && pgl_update_supported(a)) return pgl_launch_update(a, st);
     }
     switch (kind) {
         case PGL_GEMM_GRAM2: PGL_CHECK_ARG(a.W != nullptr && a.tri == 1 && a.M == a.N && a.batch_dim == nullptr); {
-            // production: persistent, DMA-staged 3-stage pipeline; PGL_GRAM_STAGES=2 selects the generic 2-stage kernel (debugging aid)
-            static const int variant = getenv("PGL_GRAM_STAGES") ? atoi(getenv("PGL_GRAM_STAGES")) : 3;
-            if (variant == 2) return launch<2, 2, 2, true, 2>(a, st);
-            if (variant == 4) return launch_gram_fine(a, st);
+            // persistent, DMA-staged 3-stage pipeline
             // launches that cannot give every CU two 8-wave items (few neurons: small models, thin shards) run as 4-wave workgroups,
             // one neuron each, two per CU: twice the items, and 53 vs 29 TFLOP/s at D = 640 with 16 neurons; at full size the
             // 8-wave pipeline (two neurons share every staged X tile) is 5 % faster
             const int n_cu = pgl_device_cus(pgl_device());
             const long ntm = (a.M + 127) / 128;
-            if (variant == 3 && ntm * (ntm + 1) / 2 * a.nbatch < 2L * n_cu) return launch_gram_fine(a, st);
+            if (ntm * (ntm + 1) / 2 * a.nbatch < 2L * n_cu) return launch_gram_fine(a, st);
             return launch_persistent<2, 2, 2, true, 3, true>(a, st);
         }
         case PGL_GEMM_PLAIN:

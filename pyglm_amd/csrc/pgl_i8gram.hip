@@ -28,7 +28,6 @@
 //   i8_crt_kernel      K residues -> mixed-radix digits (Garner) -> fp64 by Horner -> unscaled (exponent arithmetic) into the lower triangle of J
 #include "pgl_common.h"
 #include <cmath>
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -370,25 +369,22 @@ __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
 }
 
 // ------------------------------------------------------------------ int8 Gram of the planes, reduced mod p
-constexpr int TM = 256, TN = 256, BKB = 64, NST = 4;
-constexpr int STAGE_BYTES = (TM + TN) * BKB;
-constexpr int GRAM_LDS = NST * STAGE_BYTES + 32;             // + the work ticket (five ints)
+constexpr int BKB = 64;                                      // bytes (= time bins) per row of a K tile
 constexpr int KCH = 2000;                                    // K tiles between re-reductions: 128 + 128000 * 128 * 128 < 2^31
-constexpr int CH = 32;                               // clustered tile order: super-blocks of SB x SB tiles; work-list chunk per XCD
+constexpr int CH = 32;                               // flat work list (ragged groups): chunk per XCD
+constexpr int SB = 6;                                // clustered tile order: super-blocks of SB x SB tiles (measured on one box, ms per launch at cfg3:
+                                                     // 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
 
 struct GramArgs {
     const int8_t* PA;                     // [np] planes
     const int8_t* PB;                     // [G][np] planes
     int8_t* R;                            // [G][np][Dq][Dq]
     int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
-    int by_neuron;                        // work lists: XCD y owns neuron y (G == 8)
-    int sb;                               // super-block edge of the clustered tile order (tiles)
-    int idle_wave;                        // 320-tile kernel: the wave above the diagonal of a diagonal tile idles
-    int kt0;                              // 320-tile kernel only: first K tile of this pass (passes of KCH tiles; later ones accumulate)
+    int kt0;                              // first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
     long KpA; int ka0;                    // the X planes may be longer than this slice of the omega X planes: their bytes per row, first K tile
-    int accum;                            // 320-tile kernel: add to the residues already in R (a later time slice of the same product)
-    int8_t* Rx;                           // 320-tile kernel, split of the LAST plane into K quarters: quarters 1..3 of neuron g's residues
+    int accum;                            // add to the residues already in R (a later time slice of the same product)
+    int8_t* Rx;                           // split of the LAST plane into K quarters: quarters 1..3 of neuron g's residues
                                           // go to Rx[g][quarter - 1][Dq][Dq] (i8_crt adds the four); NULL: no split
 };
 
@@ -402,7 +398,7 @@ __device__ __forceinline__ int isqrt_tri_i(int t) {
 // tile t of a plane's lower triangle in CLUSTERED order: super-blocks of SB x SB tiles, row by row (boustrophedon), so that a run of
 // ~32 consecutive tiles touches few distinct 256-row strips: the workgroups of an XCD, which take such a run together, share the
 // strips through their L2 (with the plain triangular order every workgroup streamed its own two strips: 2.2 instead of 3.7 POPS)
-__device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn, const int SB = 6) {
+__device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn) {
     const int nsb = (ntm + SB - 1) / SB;
     for (int I = 0; I < nsb; ++I) {
         const int r0 = I * SB, nr = min(SB, ntm - r0);
@@ -422,133 +418,6 @@ __device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn,
 }
 
 __device__ __forceinline__ int chunk_swz(int qd) { return (0x1320 >> (4 * qd)) & 3; }     // g = {0, 2, 3, 1}
-
-__device__ __forceinline__ void i8_gram_item(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds) {
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const long plane = (long)g.Dq * g.Kp;
-    const int8_t* A = g.PA + (long)q * g.Dq * g.KpA + (long)g.ka0 * 1024;
-    const int8_t* B = g.PB + ((long)gz * g.np + q) * plane;
-    const int nkt = (int)(g.Kp / BKB);
-
-    // DMA: per K tile 512 rows x 64 B = 32 requests of 1 KiB (16 rows = one row block of the blocked plane layout: contiguous in memory,
-    // and a row block's K tiles follow each other -- with row-major planes a request was sixteen 64-byte pieces 100 KB apart and the
-    // kernel was bound by the L2 -> LDS path at 2.7 POPS).  Wave w issues requests w, w+8 (A rows) and w+16, w+24 (B rows).  Lane l
-    // fills row 16 rq + l / 4, physical 16-byte chunk l % 4, with logical chunk (l % 4) ^ g((row >> 2) & 3), g = {0, 2, 3, 1}
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const char* gp[4];
-    int loff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rq = wv + 8 * i;
-        const int lc = (lane & 3) ^ chunk_swz((lane >> 4) & 3);
-        const int8_t* base = i < 2 ? A + (long)(m0 + 16 * rq) * g.KpA : B + (long)(n0 + 16 * rq - TM) * g.Kp;
-        gp[i] = reinterpret_cast<const char*>(base) + (lane >> 2) * 64 + lc * 16;
-        loff[i] = rq * 1024;
-    }
-    // v_mfma_i32_16x16x64_i8: 8 x 4 accumulators of 16 x 16 per wave, ONE k-step per 64-byte K tile.  (On random operand bytes -- what
-    // residues are -- the package power limit sets the rate, and this form sustains 4.0 POP/s where v_mfma_i32_32x32x32_i8 sustains 3.45:
-    // tools/ubench_i8.hip; the kernel gained 11 % from the switch.)  A/B fragment = 16 rows x 64 B: lane l -> row l % 16, 16-byte chunk
-    // l / 16; the chunk swizzle above makes the 4 x 16 lane groups of ds_read_b128 conflict-free.
-    v4i acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
-    const int fr = lane & 15, fc = lane >> 4;
-    auto frag = [&](int stage, int row) {
-        const int pc = fc ^ chunk_swz((row >> 2) & 3);
-        return *reinterpret_cast<const v4i*>(lds + stage * STAGE_BYTES + row * BKB + pc * 16);
-    };
-    auto rdA = [&](int stage, int f) { return frag(stage, wm * 128 + f * 16 + fr); };
-    auto rdB = [&](int stage, int f) { return frag(stage, TM + wn * 64 + f * 16 + fr); };
-    // Pipeline: tiles are requested NST - 1 = 3 ahead, two requests per half tile (requests 0, 1 of tile kt+3 in the second half of tile
-    // kt, requests 2, 3 in the first half of tile kt+1).  A tile is two halves of 16 MFMAs: A0-3 x B, then A4-7 x B.  Fragment registers:
-    // A 8, B 2 x 4: the second half prefetches the next tile's A0-3 and B, the first half fetches its own A4-7.  Every LDS read and DMA
-    // request is issued in the shadow of an MFMA (order pinned with sched_barrier); the barrier sits BETWEEN the halves: it publishes tile
-    // kt+1 and frees the stage of tile kt-1.  Bare s_barrier: a __syncthreads() would drain the outstanding requests (vmcnt(0)).
-    long gadv = 1024, gadv2 = 1024;   // 0 once the last tile has been requested: the cursors stop and the last tile is requested again
-    auto dma_piece = [&](int stage, int i, long adv) {      // (into a stage nobody reads any more) -- no branch in front of a request
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(lds + stage * STAGE_BYTES + loff[i]), 16, 0, 0);
-        gp[i] += adv;
-    };
-    // prologue (nkt >= 4): tiles 0, 1 and the first half of tile 2
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(0, i, 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(1, i, 1024);
-    dma_piece(2, 0, 1024);
-    dma_piece(2, 1, 1024);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    v4i FA[8], FB[2][4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) { FA[f] = rdA(0, f); FB[0][f] = rdB(0, f); }
-    const double pq = (double)c_mod[q], ipq = 1.0 / pq;
-    auto reduce = [&](int v) {                              // symmetric representative of v mod p (exact: |v| < 2^31)
-        const double x = (double)v;
-        return (int)fma(-pq, rint(x * ipq), x);
-    };
-    int cur = 0;
-    auto tile = [&](auto pb_c, const int kt) {               // PB: which B buffer this tile multiplies with (compile-time index)
-        constexpr int PB = decltype(pb_c)::value;
-        const int nxt = cur == NST - 1 ? 0 : cur + 1;
-        const int dst = cur == 0 ? NST - 1 : cur - 1;          // the stage of tile kt-1 takes the first half of tile kt+3
-        const int dst2 = cur ^ 2;                               // the stage of tile kt-2 takes the second half of tile kt+2
-        if (kt + NST >= nkt) gadv = 0;
-        if (kt + NST - 1 >= nkt) gadv2 = 0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int ai = m >> 2, bj = m & 3;
-            acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
-            if (m < 4) FA[4 + m] = rdA(cur, 4 + m);
-            if (m == 7 || m == 15) dma_piece(dst2, 2 + (m >> 3), gadv2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile kt+1 has landed; the 4 requests of tile kt+2 may stay in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int ai = 4 + (m >> 2), bj = m & 3;
-            acc[ai][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(FA[ai], FB[PB][bj], acc[ai][bj], 0, 0, 0);
-            if (m < 4) FB[PB ^ 1][m] = rdB(nxt, m);
-            else if (m < 8) FA[m - 4] = rdA(nxt, m - 4);
-            if (m == 7 || m == 15) dma_piece(dst, m >> 3, gadv);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cur = nxt;
-    };
-    for (int kc = 0; kc < nkt; kc += KCH) {                 // KCH is even: every chunk starts on B buffer 0
-        const int kend = min(nkt, kc + KCH);
-        int kt = kc;
-        for (; kt + 1 < kend; kt += 2) { tile(std::integral_constant<int, 0>{}, kt); tile(std::integral_constant<int, 1>{}, kt + 1); }
-        if (kt < kend) tile(std::integral_constant<int, 0>{}, kt);        // only the very last tile of an odd total
-        if (kend < nkt) {                                           // long data sets: bring the int32 sums back below p before they can overflow
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = reduce(acc[i][j][r]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant last requests must have landed before the LDS is reused
-    // epilogue: reduce mod p and store bytes.  C/D layout of 16x16 i32: col = lane & 15, row = 4 (lane >> 4) + reg
-    int8_t* R = g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
-                const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-                R[(long)row * g.Dq + col] = (int8_t)(reduce(acc[i][j][r]) & 0xff);   // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
-            }
-}
 
 // ------------------------------------------------------------------ the same product on 320 x 320 tiles, ONE wave per SIMD
 // Under the package power limit the rate is set by the energy per operation, and a third of the 256 x 256
@@ -584,7 +453,7 @@ __device__ __forceinline__ void big_rows(v4i (&acc)[10][10], v4i (&FA)[5], v4i (
 }
 
 // kpart < 0: the whole K range of this pass; 0..3: that quarter of it (split items of the last plane, see i8_gram_kernel)
-template <int BNST>
+constexpr int BNST = 3;                                      // LDS stages (requests one tile ahead; a fourth stage measured 6.7 % slower, see pgl_k_i8_gram)
 __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz, const int q, const int tm, const int tn, char* lds, const int kpart = -1) {
     const int m0 = tm * BT, n0 = tn * BT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -643,24 +512,18 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
         if (nk < 3) gadv = 0;
 #pragma unroll
         for (int i = 0; i < 10; ++i) dma_piece(1, i);
-        if constexpr (BNST == 4) {
-            if (nk < 4) gadv = 0;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) dma_piece(2, i);
-            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // tile 0 has landed
-        } else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // tile 0 has landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // On a diagonal tile the wave that owns rows 0..159 x columns 160..319 lies wholly above the diagonal and nothing ever reads its
         // residues: it keeps its share of the requests and the barriers and issues no MFMA, no fragment read and no store (under the
         // power limit what an idle SIMD does not burn is clock for the other three: 3 % of the launch's MFMA energy)
-        if (g.idle_wave && tm == tn && wv == 1) {
+        if (tm == tn && wv == 1) {
             int cur = 0;
             for (int kt = 0; kt < nk; ++kt) {
                 const int dst = cur == 0 ? BNST - 1 : cur - 1;
                 if (kt + BNST >= nk) gadv = 0;
-                if constexpr (BNST == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -696,8 +559,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
                 if constexpr (J == 1) { if constexpr (I + 2 < 10) FA[(I + 2) % 5] = rdA(cur, I + 2); else FA[(I + 2) % 5] = rdA(nxt, I + 2 - 10); }
                 // mid-tile: tile kt+1 has landed (own requests; the 10 of tile kt+2 may stay in flight), everybody is past tile kt-1
                 if constexpr (I == 4 && J == 0) {
-                    if constexpr (BNST == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
@@ -711,7 +573,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
             cur = nxt;
         }
         };
-        if (tm == tn && g.idle_wave && wm == wn) k_loop(std::true_type{});
+        if (tm == tn && wm == wn) k_loop(std::true_type{});
         else k_loop(std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // last (redundant) requests landed; MFMA results readable
         __builtin_amdgcn_s_barrier();                      // every wave is done with the stages before the next item refills them
@@ -738,72 +600,70 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
 
 // persistent: one workgroup per CU pulls (neuron of the group, plane, tile in clustered order) items from per-XCD work lists; a workgroup
 // reads the XCC it runs on and takes the next item of that XCD's list, stealing from the next XCD when its own list is exhausted.
-//   G == 8 (every full group): XCD y owns NEURON y -- its list is that neuron's (plane, tile) items in order.  The 32 workgroups of an
-//     XCD then walk one 6 x 6 super-block of one plane together (they share its ~12 strips through their L2), and the eight XCDs walk
-//     the SAME plane and super-block at the same time, each for its own neuron: the X-plane strips (half of every item's operand
-//     stream, identical for all neurons) are fetched from HBM once and found in the memory-side cache by the other seven.
-//   otherwise: the flat item list is cut into chunks of CH, chunk c belongs to XCD c % 8.
+//   G a multiple of 8 (every full group): XCD y owns NEURONS y, y + 8, ... -- its list is, plane by plane, those neurons' tiles in order.
+//     With one neuron per XCD (G = 8: large D) the 32 workgroups of an XCD walk one 6 x 6 super-block of one plane together (they share
+//     its ~12 strips through their L2), and the eight XCDs walk the SAME plane and super-block at the same time, each for its own neuron:
+//     the X-plane strips (half of every item's operand stream, identical for all neurons) are fetched from HBM once and found in the
+//     memory-side cache by the other seven.  With several neurons per XCD (G = 16 .. 64: small D, where a plane has only a few tiles and 8
+//     neurons would not fill the CUs for more than a round or two) the whole chip still walks one plane at a time.
+//   otherwise (a ragged last group): the flat item list is cut into chunks of CH, chunk c belongs to XCD c % 8.
 // Placement is used for speed only -- any placement gives the same result.
-template <bool BIG, int BNST = 3>
-__global__ __launch_bounds__(BIG ? 256 : 512) void i8_gram_kernel(GramArgs g) {
+__global__ __launch_bounds__(256) void i8_gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    int* ticket = reinterpret_cast<int*>(lds + (BIG ? 0 : NST * STAGE_BYTES));      // (320 tiles: aliases stage 0, which is idle between items)
-    const int ntm = g.Dq / (BIG ? BT : TM);
+    int* ticket = reinterpret_cast<int*>(lds);             // (aliases stage 0, which is idle between items)
+    const int ntm = g.Dq / BT;
     const int ntiles = ntm * (ntm + 1) / 2;
-    const bool by_neuron = g.by_neuron != 0;
-    // Balance of the last rounds (by-neuron lists, 320 tiles): an XCD's list is np x ntiles equal items for 32 CUs -- at cfg3 13 x 136 = 55.25
-    // rounds, and the quarter round at the end leaves 24 of 32 CUs idle for a whole item (1.4 % of the launch).  The LAST plane's items are
+    const int npx = (g.G % 8 == 0) ? g.G / 8 : 0;          // neurons per XCD list (0: flat chunked list)
+    // Balance of the last rounds (per-XCD lists): a list is np x npx x ntiles equal items for 32 CUs -- at cfg3 13 x 136 = 55.25 rounds, and
+    // the quarter round at the end leaves 24 of 32 CUs idle for a whole item (1.4 % of the launch).  The LAST plane's items are
     // therefore cut into four K quarters each (their residues land in four slots that i8_crt adds up: modular sums are exact in any
     // order), taken 32 tiles x one quarter at a time so that co-running items still share their strips: 12 x 136 = 51 x 32 full items and
-    // 4 x 136 = 17 x 32 quarter items -- no partial round at cfg3, and never more than a quarter item of imbalance anywhere.
-    const bool split = BIG && by_neuron && g.Rx != nullptr;
-    const int nfull = split ? ntiles * (g.np - 1) : ntiles * g.np;
-    const int per_neuron = nfull + (split ? 4 * ntiles : 0);
-    const int total = per_neuron * g.G;
+    // 4 x 136 = 17 x 32 quarter items -- no partial round at cfg3, and never more than a quarter item of imbalance after the last full item.
+    const bool split = npx > 0 && g.Rx != nullptr;
+    const int nfull = ntiles * npx * (split ? g.np - 1 : g.np);
+    const int per_xcd = nfull + (split ? 4 * ntiles * npx : 0);
+    const int total = ntiles * g.np * g.G;                 // (flat list)
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
     for (;;) {
         __syncthreads();                                   // also drains the previous item's last (redundant) requests: vmcnt(0)
         if (threadIdx.x == 0) {
-            int w = -1;
+            int w = -1, y = 0;
             for (int hop = 0; hop < 8 && w < 0; ++hop) {
-                const int y = (int)((xcc + hop) & 7u);
+                y = (int)((xcc + hop) & 7u);
                 const int it = atomicAdd(&g.sched[y], 1);
-                if (by_neuron) { if (it < per_neuron) w = y * per_neuron + it; }
+                if (npx) { if (it < per_xcd) w = it; }
                 else {
                     const long cand = ((long)(it / CH) * 8 + y) * CH + it % CH;
                     if (cand < total) w = (int)cand;
                 }
             }
             if (w >= 0) {
-                int tm, tn, pair, kpart = -1, tile;
-                if (!split) { pair = w / ntiles; tile = w % ntiles; }
-                else {
-                    const int y = w / per_neuron, it = w % per_neuron;
-                    if (it < nfull) { pair = y * g.np + it / ntiles; tile = it % ntiles; }
-                    else {                                 // groups of 32 tiles (the last may be smaller), quarter-major inside a group
-                        const int r = it - nfull, grp = r / 128, within = r - grp * 128;
-                        const int tg = min(32, ntiles - grp * 32);
-                        kpart = within / tg;
-                        tile = grp * 32 + within % tg;
-                        pair = y * g.np + g.np - 1;
-                    }
+                int tm, tn, gz, q, kpart = -1, tile;
+                if (!npx) { const int pair = w / ntiles; tile = w % ntiles; gz = pair / g.np; q = pair % g.np; }
+                else if (w < nfull) {                      // plane-major, then the XCD's neurons, then the tiles of a plane
+                    const int per_plane = npx * ntiles, r = w % per_plane;
+                    q = w / per_plane; gz = y + 8 * (r / ntiles); tile = r % ntiles;
+                } else {                                   // per neuron: groups of 32 tiles (the last may be smaller), quarter-major inside a group
+                    const int r0 = w - nfull, j = r0 / (4 * ntiles), r = r0 % (4 * ntiles), grp = r / 128, within = r - grp * 128;
+                    const int tg = min(32, ntiles - grp * 32);
+                    kpart = within / tg;
+                    tile = grp * 32 + within % tg;
+                    gz = y + 8 * j; q = g.np - 1;
                 }
-                clustered_tile(tile, ntm, tm, tn, g.sb);
-                ticket[1] = pair; ticket[2] = tm; ticket[3] = tn; ticket[4] = kpart;
+                clustered_tile(tile, ntm, tm, tn);
+                ticket[1] = gz; ticket[2] = tm; ticket[3] = tn; ticket[4] = kpart; ticket[5] = q;
             }
             ticket[0] = w;
         }
         __syncthreads();
         if (ticket[0] < 0) break;
-        const int pair = __builtin_amdgcn_readfirstlane(ticket[1]);
+        const int gz = __builtin_amdgcn_readfirstlane(ticket[1]), q = __builtin_amdgcn_readfirstlane(ticket[5]);
         const int tm = __builtin_amdgcn_readfirstlane(ticket[2]), tn = __builtin_amdgcn_readfirstlane(ticket[3]);
-        if constexpr (BIG) {
-            const int kpart = __builtin_amdgcn_readfirstlane(ticket[4]);
-            __syncthreads();                               // the ticket lives in stage 0: everybody has read it before the first request lands there
-            i8_gram_item_big<BNST>(g, pair / g.np, pair % g.np, tm, tn, lds, kpart);
-        } else i8_gram_item(g, pair / g.np, pair % g.np, tm, tn, lds);
+        const int kpart = __builtin_amdgcn_readfirstlane(ticket[4]);
+        __syncthreads();                                   // the ticket lives in stage 0: everybody has read it before the first request lands there
+        i8_gram_item_big(g, gz, q, tm, tn, lds, kpart);
     }
 }
 
@@ -892,13 +752,7 @@ __global__ __launch_bounds__(256) void i8_crt_kernel(CrtArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------ host side
-// Tile edge of the product kernel: 320 (one wave per SIMD, accumulators in both register files) or 256 (two waves per SIMD);
-// PGL_I8_TILE=256 selects the latter.  Planes and residues are padded to a multiple of it (pgl_i8_padded_rows).
-static int pgl_i8_tile() {
-    static const int t = [] { const char* e = getenv("PGL_I8_TILE"); return (e && atoi(e) == 256) ? 256 : 320; }();
-    return t;
-}
-int pgl_k_i8_padded_rows(int D) { const int t = pgl_i8_tile(); return (D + t - 1) / t * t; }
+int pgl_k_i8_padded_rows(int D) { return (D + BT - 1) / BT * BT; }     // planes and residues are padded to the product kernel's tile edge
 
 // time bins per plane row: a multiple of the 64-byte K tile, at least four tiles (the Gram pipeline keeps three requested ahead)
 static long pgl_i8_kp(int T) { const long k = ((long)T + 63) / 64 * 64; return k < 256 ? 256 : k; }
@@ -927,6 +781,8 @@ int pgl_k_i8_min_planes(int T) {
 }
 
 long pgl_k_i8_kp(int T) { return pgl_i8_kp(T); }
+// is the last plane of a product over G neurons cut into K quarters (whose residues go to the Rx slots)?  Groups that fill the per-XCD lists only
+static bool pgl_k_i8_split(int G, int nplanes) { return G % 8 == 0 && nplanes >= 2; }
 size_t pgl_k_i8_plane_bytes(int D, int T) {
     const long Dq = pgl_k_i8_padded_rows(D), Kp = pgl_i8_kp(T);
     return (size_t)NP * Dq * Kp;
@@ -1003,18 +859,20 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
                     int nplanes, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
-    PlaneArgs a{X, ldx, transposed, Om, ldo, scale, P, T, D, Dq, Kp, nplanes};
     // 512 time bins per workgroup: 8 KiB contiguous per plane and row block.  Measured on one box, ms per group of 8 at cfg3, with the
     // non-temporal stores: 256 bins 13.6, 512 bins 12.5, 1024 bins 12.4 (with ordinary stores the three were within 2 %).
     const bool aligned = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
-    static const bool lds_tile = getenv("PGL_PLANES_LDS") != nullptr;                  // A/B switch: the LDS-tile kernel on Xt as well
-    if (transposed && aligned && !lds_tile && G <= CS_G)       // (the register kernel stages at most CS_G weight columns; more: the tile kernel)
-        // measured on one box per variant pair, ms per group of 8 at cfg3 (the LDS-tile kernel on Xt: 11.9): 768 threads 11.3-11.4, 512 10.7-10.8
-        // (137 VGPRs, one workgroup per CU; forced to 128 VGPRs with 16 spills: 11.3-11.4), 256 9.85-10.1, 128 10.3-10.6
-        hipLaunchKernelGGL(i8_planes_t_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, G);
-    else
-        hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, G);
-    PGL_CHECK_LAUNCH();
+    for (int g0 = 0; g0 < G; g0 += CS_G) {                     // (the kernels stage at most CS_G weight columns; larger groups go in pieces)
+        const int gz = G - g0 < CS_G ? G - g0 : CS_G;
+        PlaneArgs a{X, ldx, transposed, Om ? Om + g0 : nullptr, ldo, scale + (long)g0 * D, P + (long)g0 * nplanes * Dq * Kp, T, D, Dq, Kp, nplanes};
+        if (transposed && aligned)
+            // measured on one box per variant pair, ms per group of 8 at cfg3 (the LDS-tile kernel on Xt: 11.9): 768 threads 11.3-11.4, 512 10.7-10.8
+            // (137 VGPRs, one workgroup per CU; forced to 128 VGPRs with 16 spills: 11.3-11.4), 256 9.85-10.1, 128 10.3-10.6
+            hipLaunchKernelGGL(i8_planes_t_kernel<256>, dim3((unsigned)((Kp + 255) / 256), Dq / PT_D), dim3(256), 0, st, a, gz);
+        else
+            hipLaunchKernelGGL(i8_planes_kernel<512>, dim3((unsigned)((Kp + 511) / 512), Dq / PT_D), dim3(512), 0, st, a, gz);
+        PGL_CHECK_LAUNCH();
+    }
     return PGL_OK;
 }
 
@@ -1023,51 +881,36 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
 int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t* R, int8_t* Rx, int T, int D, int G, int nplanes, int accumulate, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
-    const bool big = pgl_i8_tile() == BT;
     if (KpA <= 0) { KpA = Kp; ka0 = 0; }
     if (KpA % BKB != 0 || (long)(ka0 + Kp / BKB) * BKB > KpA) { pgl_set_error("i8 gram: slice of %ld bytes at tile %d outside the X planes (%ld)", Kp, ka0, KpA); return PGL_ERR_ARG; }
-    if (accumulate && !big) { pgl_set_error("i8 gram: time slices need the 320-tile kernel (PGL_I8_TILE=256 is set)"); return PGL_ERR_ARG; }
-    // LDS stages of the 320-tile kernel: 3 (requests one tile ahead).  A fourth stage (two tiles ahead, all 160 KiB) measured 6.7 % SLOWER on
-    // real planes (107.2 vs 100.5 ms per launch of 8 neurons at cfg3): the 32 workgroups of an XCD then hold 3 x 40 KiB in flight each, which
-    // is the whole 4 MiB L2, and the strips they share fall out of it.  PGL_I8_STAGES=4 keeps the variant measurable.
-    static const int big_stages = [] { const char* e = getenv("PGL_I8_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
-    static PglPerDevice attr, attr_big3, attr_big4;
-    if (big && big_stages == 4) { if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<true, 4>), 4 * BSTAGE, attr_big4)) return rc; }
-    else if (big) { if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<true, 3>), 3 * BSTAGE, attr_big3)) return rc; }
-    else if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel<false>), GRAM_LDS, attr)) return rc;
+    // Three LDS stages (requests one tile ahead).  A fourth stage (two tiles ahead, all 160 KiB) measured 6.7 % SLOWER on real planes (107.2 vs
+    // 100.5 ms per launch of 8 neurons at cfg3): the 32 workgroups of an XCD then hold 3 x 40 KiB in flight each, which is the whole 4 MiB
+    // L2, and the strips they share fall out of it.
+    static PglPerDevice attr;
+    if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(i8_gram_kernel), BNST * BSTAGE, attr)) return rc;
     const int n_cu = pgl_device_cus(pgl_device());
-    const int ntm = Dq / (big ? BT : TM), ntiles = ntm * (ntm + 1) / 2;
+    const int ntm = Dq / BT, ntiles = ntm * (ntm + 1) / 2;
     const long total = (long)ntiles * nplanes * G;
     if (total <= 0) return PGL_OK;
-    if (total > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
+    if (total * 4 > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
     const unsigned grid = (unsigned)(total < n_cu ? total : n_cu);
     const int nkt = (int)(Kp / BKB);
-    for (int kt0 = 0; kt0 < (big ? nkt : 1); kt0 += KCH) {
-        static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();   // A/B switch: "chunk"
-        // super-blocks of 6 x 6 tiles (measured on one box, ms per launch: 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
-        static const bool idle_off = [] { const char* e = getenv("PGL_I8_IDLE"); return e && e[0] == '0'; }();                  // A/B switch
-        static const bool split_off = [] { const char* e = getenv("PGL_I8_SPLIT"); return e && e[0] == '0'; }();               // A/B switch
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, (G == 8 && !map_chunks) ? 1 : 0, 6, idle_off ? 0 : 1, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0,
-                   (big && !split_off && nplanes >= 2) ? Rx : nullptr};
+    for (int kt0 = 0; kt0 < nkt; kt0 += KCH) {
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
-        if (big && big_stages == 4) hipLaunchKernelGGL((i8_gram_kernel<true, 4>), dim3(grid), dim3(256), 4 * BSTAGE, st, g);
-        else if (big) hipLaunchKernelGGL((i8_gram_kernel<true, 3>), dim3(grid), dim3(256), 3 * BSTAGE, st, g);
-        else hipLaunchKernelGGL(i8_gram_kernel<false>, dim3(grid), dim3(512), GRAM_LDS, st, g);
+        hipLaunchKernelGGL(i8_gram_kernel, dim3(grid), dim3(256), BNST * BSTAGE, st, g);
         PGL_CHECK_LAUNCH();
     }
     return PGL_OK;
 }
 
-// Rx: the three extra residue slots per neuron of a product that ran with the last plane split (pgl_k_i8_gram with the same Rx, G == 8
-// and the 320-tile kernel); NULL otherwise
+// Rx: the three extra residue slots per neuron of a product that ran with the last plane split (pgl_k_i8_gram with the same Rx and a group
+// that is a multiple of 8); NULL otherwise
 int pgl_k_i8_crt(const int8_t* R, const int8_t* Rx, const double* sA, const double* sB, double* J, long ldj, long strideJ, int D, int G, int nplanes,
                  int accumulate, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     if (G <= 0) return PGL_OK;
-    static const bool split_off = [] { const char* e = getenv("PGL_I8_SPLIT"); return e && e[0] == '0'; }();
-    static const bool map_chunks = [] { const char* e = getenv("PGL_I8_MAP"); return e && e[0] == 'c'; }();
-    const bool split = Rx != nullptr && !split_off && !map_chunks && G == 8 && nplanes >= 2 && pgl_i8_tile() == BT;       // = the condition in i8_gram_kernel
-    CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes, split ? Rx : nullptr};
+    CrtArgs c{R, sA, sB, J, ldj, strideJ, D, Dq, G, accumulate, nplanes, (Rx != nullptr && pgl_k_i8_split(G, nplanes)) ? Rx : nullptr};     // = the condition in pgl_k_i8_gram
     hipLaunchKernelGGL(i8_crt_kernel, dim3((D + 1023) / 1024, D, G), dim3(256), 0, st, c);
     PGL_CHECK_LAUNCH();
     return PGL_OK;

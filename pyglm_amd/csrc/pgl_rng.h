@@ -3,8 +3,8 @@
 // Stands where the reference calls the third-party `pypolyagamma.pgdrawvpar`
 // (/root/reference/pyglm/regression.py:501-508; shapes b = b_func(y) are real-valued, :479-489).  PG(1, z): Polson, Scott & Windle
 // (2013) Devroye-style alternating-series sampler (truncation t = 0.64).  PG(b, z) for any b > 0 by infinite divisibility:
-// floor(b) <= 12 draws of PG(1, z) plus, for the fractional part (or for the whole of b > 12, where that is cheaper and free of
-// wave divergence), the sum-of-gammas representation  omega = 1/(2 pi^2) sum_k g_k / ((k - 1/2)^2 + z^2 / (4 pi^2)),
+// floor(b) <= 64 EXACT draws of PG(1, z) plus, for the fractional part only (or for the whole of b > 64 -- counts that large are rare and
+// the cost of the exact sum grows with b), the sum-of-gammas representation  omega = 1/(2 pi^2) sum_k g_k / ((k - 1/2)^2 + z^2 / (4 pi^2)),
 // g_k ~ Gamma(b, 1), truncated at 32 terms with the remainder drawn as ONE gamma variate matched to the remainder's exact mean and
 // variance (it carries 0.6 % of the mean; its third cumulant is off by 1e-9 of the total) -- the third-party sampler itself truncates
 // the same series, uncorrected, for b < 1.
@@ -148,7 +148,7 @@ __device__ __forceinline__ double pgl_gamma(double alpha, PglPhilox& r) {
 }
 
 #define PGL_PG_SERIES_TERMS 32
-#define PGL_PG_DEVROYE_MAX 12
+#define PGL_PG_DEVROYE_MAX 64
 
 // sum_{k > K} ((k - 1/2)^2 + c)^-p for p = 1, 2 by the midpoint-rule (Euler-Maclaurin) identity
 //     sum_{k > K} phi(k - 1/2) = int_K^inf phi + phi'(K) / 24 - 7 phi'''(K) / 5760 + O(phi^(5)(K)):   relative error < 2e-9 at K = 32

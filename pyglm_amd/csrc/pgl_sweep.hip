@@ -11,7 +11,6 @@
 #include "pgl_common.h"
 #include "../../include/pyglm_hip.h"
 #include <cmath>
-#include <cstdlib>
 #include <tuple>
 #include <vector>
 
@@ -157,7 +156,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         PGL_CHECK_ARG(!d.int8 || (d.sA && (d.PA || s->i8_PAs) && (d.planes > 0 || s->planes > 0)));      // (no resident X planes: converted per slice -- or once per group for the whole data set -- into i8_PAs)
         any_i8 = any_i8 || d.int8;
     }
-    PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= 8 && s->obs != 2));
+    PGL_CHECK_ARG(!any_i8 || (s->i8_PB && s->i8_R && s->i8_stat && s->i8_group >= 1 && s->i8_group <= PGL_I8_MAX_GROUP && s->obs != 2));
     Clock clk{s->times, st};
 
     // ---- activation of the whole shard, PG draw / kappa / log-likelihood (regression.py:195-201, 491-511)
@@ -261,8 +260,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 // fp64 MFMA contraction of the squared operands, ss[n][j] = sum_t omega_nt^2 x_tj^2 -- X is read once per batch instead of once
                 // per group of 8 neurons (215 ms of column-statistics passes per sweep at BASELINE configs[2]) --, T cut into slices whose partial
                 // sums borrow the (idle) residue buffer and are added in slice order, like the border sums above.
-                static const bool norm_gemm = [] { const char* e = getenv("PGL_I8_NORM_GEMM"); return !(e && e[0] == '0'); }();     // A/B switch
-                const bool batch_norms = norm_gemm && d.xmax && s->i8_norm && s0 % 2 == 0;
+                const bool batch_norms = d.xmax && s->i8_norm && s0 % 2 == 0;
                 const long part = (long)r_up(s->nb, 2) * Dp;
                 double* ssb = s->i8_norm;                          // [nb rounded up to even][Dp] sums of squares of this batch's columns
                 double* ommax = s->i8_norm + part;                 // [nloc] largest omega of every local neuron
@@ -304,15 +302,17 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     if (batch_norms) {
                         RC(pgl_k_i8_scales_bound(ssb + (long)g0 * Dp, Dp, ommax + s0 + g0, d.xmax, (int)D, gz, d.T, np, sB, st));
                     } else {
-                        // one pass over X per group (the statistics pass borrows the residue buffer for its per-chunk partials: the previous
+                        // one pass over X per 8 neurons (the statistics pass borrows the residue buffer for its per-chunk partials: the previous
                         // group's CRT has read it, this group's products have not written it yet)
-                        static const bool split_t = [] { const char* e = getenv("PGL_I8_STATS_SPLIT"); return !(e && e[0] == '0'); }();     // A/B switch
                         const size_t r_bytes = (size_t)gz * np * pgl_k_i8_padded_rows((int)D) * pgl_k_i8_padded_rows((int)D);
-                        if (split_t && pgl_k_i8_stats_scratch_doubles((int)D, gz) * sizeof(double) <= r_bytes)
-                            RC(pgl_k_i8_colstats_scales(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, np, reinterpret_cast<double*>(s->i8_R), sB, st));
-                        else {
-                            RC(pgl_k_i8_colstats(d.X, Dp, om, 2 * ldn, d.T, (int)D, gz, amax, ss, st));
-                            RC(pgl_k_i8_scales(amax, ss, (long)gz * D, d.T, np, sB, st));
+                        for (int c0 = 0; c0 < gz; c0 += 8) {
+                            const int cz = 8 < gz - c0 ? 8 : gz - c0;
+                            if (pgl_k_i8_stats_scratch_doubles((int)D, cz) * sizeof(double) <= r_bytes)
+                                RC(pgl_k_i8_colstats_scales(d.X, Dp, om + c0, 2 * ldn, d.T, (int)D, cz, np, reinterpret_cast<double*>(s->i8_R), sB + (long)c0 * D, st));
+                            else {
+                                RC(pgl_k_i8_colstats(d.X, Dp, om + c0, 2 * ldn, d.T, (int)D, cz, amax, ss, st));
+                                RC(pgl_k_i8_scales(amax, ss, (long)cz * D, d.T, np, sB + (long)c0 * D, st));
+                            }
                         }
                     }
                     clk.toc(m);
@@ -360,8 +360,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
             }
             // initial sweep on S0 = {bias} U {active blocks}, in chunks of 512 pivots (rank-512 passes); the lists come from the device
             RC(pgl_k_flip_pivot_list(fs, s->act, D + 1, s->na, st));
-            static const int ck_env = [] { const char* e = getenv("PGL_FLIP_CHUNK"); return e ? atoi(e) : 0; }();      // A/B switch
-            const int ck = (ck_env >= 16 && ck_env <= kmax) ? ck_env : kmax;
+            const int ck = kmax;
             long rows = s->init_rows_bound > 0 && s->init_rows_bound <= D + 1 ? s->init_rows_bound : D + 1;
             for (int c = 0; (long)c * ck < rows; ++c) {
                 const long left = rows - (long)c * ck;
@@ -373,8 +372,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
             const int nwin = (N + R - 1) / R;
             // windows in pairs: one pass over the trailing tableau for two windows' panels (pgl_k_flip_apply_pair); its four counters per
             // neuron live in the pivot-list buffer, which is free between the initial sweep and the weight draw
-            static const bool pair_env = [] { const char* e = getenv("PGL_FLIP_PAIR"); return !(e && e[0] == '0'); }();     // A/B switch
-            const bool pair = pair_env && s->visit_order;
+            const bool pair = s->visit_order && !s->flip_single_pass;
             for (int w = 0; w < nwin; ++w) {
                 auto m = clk.tic(ST_FDEC);
                 RC(pgl_k_flip_decide(fs, w, st));

@@ -19,7 +19,6 @@
 // The summation order of every output element is the one of the generic kernel (K tiles in order, four k per MFMA), so the two give the
 // same bits; tests/test_gpu_update.py holds them against each other.
 #include "pgl_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -459,8 +458,7 @@ int launch_update(const PglGemmArgs& a0, hipStream_t st) {
         nt += hi + 1;
     }
     u.ntiles = (int)nt;
-    static const int stagger_env = [] { const char* e = getenv("PGL_UPD_STAGGER"); return e ? atoi(e) : -1; }();       // A/B switch
-    u.stagger = stagger_env >= 0 ? stagger_env : u.cinit;
+    u.stagger = u.cinit;
     const long total = nt * a.nbatch;
     if (total <= 0) return PGL_OK;
     if (total > 0x7fffffffL) { pgl_set_error("update: %ld work items", total); return PGL_ERR_ARG; }

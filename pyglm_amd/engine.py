@@ -94,10 +94,13 @@ class GibbsEngine(object):
     OBS = {"bernoulli": 0, "negbin": 1, "gaussian": 2}
 
     def __init__(self, N, B, n0=0, n1=None, device=None, obs="bernoulli", xi=1.0, batch=None, mem_budget_bytes=None,
-                 design_only=False, visit_order=True, gram=None, likelihood_only=False, planes=None):
+                 design_only=False, visit_order=True, gram=None, likelihood_only=False, planes=None, i8_group=None, i8_slice=None,
+                 i8_resident=None, device_share=1):
         """device: torch device of this shard (default: the process's current GPU).  design_only: only the design matrix is kept (basis
         convolution).  likelihood_only: activation / log-likelihood / means only -- no sweep buffers, no residue planes (a held-out data
-        set costs X', Y and Psi, nothing else)."""
+        set costs X', Y and Psi, nothing else).  i8_group / i8_slice / i8_resident: override the integer Gram's plan (_i8_plan) -- neurons
+        per product launch, time bins per slice, X's planes kept (True) or converted per slice (False); tests and probes.  device_share: number of
+        engines (ranks) that share this GPU -- each then stays inside an equal share of its memory (bench.py's one-GPU dry run of N ranks)."""
         if not torch.cuda.is_available():
             raise _lib.PglError("pyglm_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         _lib.load()
@@ -109,6 +112,8 @@ class GibbsEngine(object):
         if self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.dev):
+            self._i8_over = dict(group=i8_group, slice=i8_slice, resident=i8_resident)
+            self._device_share = max(1, int(device_share))
             self._init(N, B, obs, xi, batch, mem_budget_bytes, design_only, visit_order, gram, likelihood_only, planes)
 
     def _init(self, N, B, obs, xi, batch, mem_budget_bytes, design_only, visit_order, gram, likelihood_only, planes):
@@ -125,12 +130,10 @@ class GibbsEngine(object):
         # CRT, pgl_i8_*; operands rounded to integers scaled from their column norms -- measured error several times below the fp64
         # kernel's own); "auto" (default) takes the integer path per data set where it is the faster one and its
         # planes -- whole or in time slices -- fit in memory (_i8_plan)
-        import os
-        self.gram = gram or os.environ.get("PGL_GRAM", "auto")
+        self.gram = gram or "auto"
         assert self.gram in ("auto", "fp64", "int8")
-        # number of residue planes (moduli) of the integer path: an int, or None / PGL_I8_PLANES unset = pgl_i8_min_planes (13: integer
-        # column norms of 2^50, measured error several times below the fp64 kernel's own); every further plane buys 4 more bits
-        planes = planes or os.environ.get("PGL_I8_PLANES")
+        # number of residue planes (moduli) of the integer path: an int, or None = pgl_i8_min_planes (13: integer column norms of 2^50,
+        # measured error several times below the fp64 kernel's own); every further plane buys 4 more bits
         self.planes = int(planes) if planes else None
         assert self.planes is None or 1 <= self.planes <= _lib.load().pgl_i8_max_planes()
         self._i8_scratch = None
@@ -152,6 +155,7 @@ class GibbsEngine(object):
             self._alloc_shard()
             if batch is not None:
                 self._ensure_batch()
+        self.flip_single_pass = False   # True: one pass over the trailing tableau per proposal window instead of per pair (same bits; tests)
         self.keep_logodds = False       # True: sweep() leaves the flip log-odds in self.logodds (parity tests)
         self.logodds = None
         self.profile = False            # True: every stage of pgl_sweep is timed with HIP events; a collection of stage names: only those
@@ -201,11 +205,10 @@ class GibbsEngine(object):
         return torch.zeros(*shape, dtype=dtype, device=self.dev)
 
     def _free_bytes(self):
-        """memory this engine may still take on its GPU.  Ranks that share one device (bench.py with PGL_BENCH_DEVICE: PGL_DEVICE_SHARE =
-        their number) each stay inside an equal share of it, whatever the others have allocated so far."""
-        import os
+        """memory this engine may still take on its GPU.  Ranks that share one device (device_share = their number) each stay inside an
+        equal share of it, whatever the others have allocated so far."""
         free, total = torch.cuda.mem_get_info(self.dev)
-        share = max(1, int(os.environ.get("PGL_DEVICE_SHARE", "1")))
+        share = self._device_share
         if share > 1:
             free = min(free, int(total * 0.94) // share - torch.cuda.memory_reserved(self.dev))
         return max(0, free)
@@ -338,7 +341,7 @@ class GibbsEngine(object):
         return ds
 
     # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
-    I8_GROUP = 8          # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
+    I8_GROUPS = (64, 32, 16, 8, 4, 2, 1)     # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
     I8_MIN_D, I8_MIN_T = 1024, 2048
     I8_SMALL_D, I8_SMALL_T = 640, 16384      # between 640 and 1024 columns: only where the 320-tile padding leaves a gain (_i8_pays)
 
@@ -354,14 +357,31 @@ class GibbsEngine(object):
         t8 = planes * (nq * (nq + 1) // 2 * 320 * 320 * 1.12e-15 + nq * 320 * 1.9e-13)
         return t8 < 0.9 * t64
 
+    @staticmethod
+    def _i8_rounds(G, ntiles, planes, cus=256):
+        """item-times one product launch over G neurons takes (pgl_i8gram.hip): G a multiple of 8 -> per-XCD lists (cus / 8 workgroups each)
+        of (planes - 1) x G/8 x ntiles whole items, then the last plane's items in K quarters; otherwise one flat list.  What the choice of
+        the group size goes by: 8 neurons of a small model (BASELINE configs[1]: 3 tiles per plane, 312 items for 256 CUs) leave the chip
+        half idle in their second round, 64 run 9.75 full rounds."""
+        if G % 8:
+            return float(-(-ntiles * planes * G // cus))
+        per = cus // 8
+        npx = G // 8
+        full, quarters = ntiles * npx * (planes - 1), 4 * ntiles * npx
+        t, rf = divmod(full, per)
+        if rf:
+            t += 1
+            quarters = max(0, quarters - 4 * (per - rf))
+        return t + -(-quarters // per) / 4.0
+
     def _i8_plan(self, T):
         """-> None (this data set's Gram runs on the fp64 kernel) or how it goes through the int8 MFMA: dict(planes, resident, G, slice).
         The integer path is taken if asked for, or (auto) at shapes where it is the faster one (320 x 320 tiles, 13 planes: not for small D
         or short T).  Memory decides the rest: X's planes stay resident if they are a small part of what is free; the planes of omega_g X
-        for a group of G <= 8 neurons and the group's residues must fit -- if a whole data set's do not (BASELINE configs[4]: 86 GB of
-        planes per neuron), the product runs in time slices that add up in the residues (pgl_sweep_t.i8_slice), and only if not even a
-        short slice fits does the data set fall back to the fp64 kernel (with a warning)."""
-        import os
+        for a group of G neurons and the group's residues must fit -- G = 8 (one neuron per XCD) at large D, more where a plane has only
+        a few tiles (_i8_rounds); if a whole data set's planes do not fit (BASELINE configs[4]: 86 GB of planes per neuron), the product
+        runs in time slices that add up in the residues (pgl_sweep_t.i8_slice), and only if not even a short slice fits does the data set
+        fall back to the fp64 kernel (with a warning)."""
         if self.obs == 2 or self.design_only or self.likelihood_only or self.gram == "fp64":
             return None
         if self.gram != "int8" and (T < self.I8_MIN_T or (self.D < self.I8_MIN_D and not self._i8_pays(T))):
@@ -370,38 +390,45 @@ class GibbsEngine(object):
         planes = self.planes or lib.pgl_i8_min_planes(T)
         if lib.pgl_i8_norm_bits(planes, T) < 8:
             raise ValueError("%d residue planes cannot hold T = %d time bins" % (planes, T))
+        over = self._i8_over
         mp = lib.pgl_i8_max_planes()
+        Dq = lib.pgl_i8_padded_rows(self.D)
         pa_full = lib.pgl_i8_plane_bytes(self.D, T) // mp * planes
         kp_full = max(256, -(-T // 64) * 64)                     # bytes per plane row: the bins, padded to the 64-byte K tile
-        per_bin = planes * lib.pgl_i8_padded_rows(self.D)        # bytes of one time bin in one set of planes
+        per_bin = planes * Dq                                    # bytes of one time bin in one set of planes
         r1 = lib.pgl_i8_residue_bytes(self.D) // mp * planes
         free = self._free_bytes()
         have = self._i8_scratch[0] if self._i8_scratch else 0
         budget = int(0.85 * free) + have
-        gmax = int(max(1, min(int(os.environ.get("PGL_I8_GROUP", self.I8_GROUP)), self.nb or self.nloc)))
-        forced = os.environ.get("PGL_I8_SLICE")               # test / probe hook: time bins per slice
-        cands = []
-        keep = pa_full <= 0.3 * free and os.environ.get("PGL_I8_RESIDENT", "1") != "0"      # (PGL_I8_RESIDENT=0: test hook)
+        gmax = int(max(1, min(over["group"] or self.I8_GROUPS[0], self.nb or self.nloc)))
+        groups = [G for G in self.I8_GROUPS if G <= gmax] or [1]
+        if over["group"]:
+            groups = [G for G in groups if G == min(over["group"], gmax)] or [min(over["group"], gmax)]
+        keep = pa_full <= 0.3 * free if over["resident"] is None else bool(over["resident"])
+        ntiles = (Dq // 320) * (Dq // 320 + 1) // 2
+        cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+
+        def fit(resident, G):      # time bins per slice that fit with this choice
+            fixed = (pa_full if resident else 0) + G * r1 + (3 * G * Dq * Dq if G % 8 == 0 else 0)
+            return int((budget - fixed) // (per_bin * (G + (0 if resident else 1))))
+        if over["slice"]:
+            S = max(64, int(over["slice"]) // 64 * 64)
+            return dict(planes=planes, resident=keep, G=groups[0] if over["group"] else min(gmax, 8), slice=S if S < T else 0)
         for resident in ((True, False) if keep else (False,)):
-            for G in (8, 4, 2, 1):
-                if G > gmax:
-                    continue
-                fixed = (pa_full if resident else 0) + G * r1 + (3 * G * lib.pgl_i8_padded_rows(self.D) ** 2 if G == 8 else 0)
-                S = (budget - fixed) // (per_bin * (G + (0 if resident else 1)))
-                cands.append((resident, G, int(S)))
-        if forced:
-            S = max(64, int(forced) // 64 * 64)
-            return dict(planes=planes, resident=cands[0][0], G=min(gmax, 8), slice=S if S < T else 0)
-        for resident, G, S in cands:
-            if S >= kp_full:
-                return dict(planes=planes, resident=resident, G=G, slice=0)
+            ok = [G for G in groups if fit(resident, G) >= kp_full]
+            if ok:
+                # per-neuron cost of a launch in item-times; the smallest group within 1.5 % of the best (memory is better spent elsewhere)
+                cost = {G: self._i8_rounds(G, ntiles, planes, cus) / G for G in ok}
+                best = min(cost.values())
+                return dict(planes=planes, resident=resident, G=min(G for G in ok if cost[G] <= 1.015 * best), slice=0)
+        cands = [(resident, G, fit(resident, G)) for resident in ((True, False) if keep else (False,)) for G in groups if G <= 8]
         cands = [c for c in cands if c[2] >= 16384]
         if not cands:
+            if self.gram == "int8":
+                raise _lib.PglError("gram='int8': the residue planes do not fit")
             import warnings
             warnings.warn("gram='auto': not even a 16384-bin slice of the residue planes of this data set (D = %d, T = %d) fits in the %.0f GB free "
                           "on %s; its likelihood Gram runs on the fp64 MFMA kernel" % (self.D, T, free / 1e9, self.dev), RuntimeWarning, stacklevel=3)
-            if self.gram == "int8":
-                raise _lib.PglError("gram='int8': the residue planes do not fit")
             return None
         resident, G, S = max(cands, key=lambda c: (min(c[2], kp_full // 2), c[1]))       # long slices first (at least two are needed anyway), then large groups
         nsl = -(-T // (S // 1024 * 1024))
@@ -410,29 +437,35 @@ class GibbsEngine(object):
 
     def _i8_reserve(self, T, plan):
         """scratch for the planes of omega_g X (one time slice of them) and the residues of a group of G neurons -- and for a slice of X's own
-        planes where those are not resident -- sized for the largest need seen so far"""
+        planes where those are not resident -- sized for the largest need seen so far.  One slice length per engine (pgl_sweep_t.i8_slice): the
+        shortest any of its data sets needs; a data set no longer than that runs unsliced, and slices of any length add up to the same bits,
+        so data sets planned with different slicing simply share the shorter one."""
         lib = _lib.load()
         mp, planes = lib.pgl_i8_max_planes(), plan["planes"]
-        Ts = plan["slice"] or T
+        S, G, T0 = plan["slice"], plan["G"], 0
+        if self._i8_scratch:
+            S0 = self._i8_scratch[6]
+            if S0 and (not S or S0 < S):
+                S = S0
+        Ts = min(S, T) if S else T
         pb1, r1 = lib.pgl_i8_plane_bytes(self.D, Ts) // mp * planes, lib.pgl_i8_residue_bytes(self.D) // mp * planes
-        G, pas, T0 = plan["G"], (0 if plan["resident"] else pb1), 0
+        pas = 0 if plan["resident"] else pb1
         if self._i8_scratch:
             _, T0, G0, PB, R, _, S0, PAs = self._i8_scratch[:8]
-            if G0 == G and S0 == plan["slice"] and T0 >= T and PB.numel() >= G * pb1 and R.numel() >= G * r1 and (PAs.numel() if PAs is not None else 0) >= pas:
+            if G0 == G and S0 == S and T0 >= T and PB.numel() >= G * pb1 and R.numel() >= G * r1 and (PAs.numel() if PAs is not None else 0) >= pas:
                 return
-            if S0 != plan["slice"] and (S0 or plan["slice"]):
-                raise _lib.PglError("data sets with different time slicing of the integer Gram in one engine (add the largest first)")
             pb1, r1 = max(pb1, PB.numel() // G0), max(r1, R.numel() // G0)      # keep what earlier data sets need
             pas = max(pas, PAs.numel() if PAs is not None else 0)
             G = min(G, G0)
         self._i8_scratch = None
         torch.cuda.empty_cache()
+        Dq = lib.pgl_i8_padded_rows(self.D)
         self._i8_scratch = (G * (pb1 + r1) + pas, max(T, T0), G, torch.empty(G * pb1, dtype=torch.int8, device=self.dev),
                             torch.empty(G * r1, dtype=torch.int8, device=self.dev),
                             self._z(3, G, self.D),          # per group: column maxima, sums of squares, scales of omega_g X
-                            plan["slice"], torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None,
-                            # the three extra residue slots per neuron of the K-quarter split of the last plane (full groups of 8 only)
-                            torch.empty(3 * G * lib.pgl_i8_padded_rows(self.D) ** 2, dtype=torch.int8, device=self.dev) if G == 8 else None)
+                            S, torch.empty(pas, dtype=torch.int8, device=self.dev) if pas else None,
+                            # the three extra residue slots per neuron of the K-quarter split of the last plane (groups that fill the per-XCD lists)
+                            torch.empty(3 * G * Dq * Dq, dtype=torch.int8, device=self.dev) if G % 8 == 0 else None)
 
     @_on_device
     def drop_int8(self, i):
@@ -520,7 +553,8 @@ class GibbsEngine(object):
 
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
     @_on_device
-    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None, nrun=0):
+    def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None, nrun=0,
+              after_queue=None, readback=True):
         """regression.py:265-280 for every local neuron, as ONE call of pgl_sweep (include/pyglm_hip.h): the whole sweep is queued on the
         stream without a host synchronisation.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in natural form
         (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
@@ -528,7 +562,11 @@ class GibbsEngine(object):
         host_overlap: optional callable run on the host while the GPU works through the queue (seconds at full size), e.g. to draw the
         next sweep's permutations.
         nrun: sweep only the first nrun local neurons (what one rank of a larger job would do, timed on this GPU -- bench.py's
-        scaling_proxy); the returned rows of the others are their input."""
+        scaling_proxy); the returned rows of the others are their input.
+        after_queue: optional callable(engine) run right after the sweep has been queued, with the engine's device current -- the
+        population model packs the new rows (packed_state) and starts its all_gather there, behind the sweep on the same stream.
+        readback=False: the new (a, W, b) stay on the device (a_dev / W_dev / b_dev, packed_state); only ll and the status flags come
+        back: returns (None, None, None, ll)."""
         nloc, N, B, D = self.nloc, self.N, self.B, self.D
         if self.likelihood_only or self.design_only:
             raise _lib.PglError("this engine was built without sweep buffers (likelihood_only / design_only)")
@@ -582,23 +620,39 @@ class GibbsEngine(object):
                         ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
                         int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, ptr(self._i8_norm) if i8 else None, int(nrun),
                         int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
-                        ctypes.pointer(self._times) if self.profile else None)
+                        int(self.flip_single_pass), ctypes.pointer(self._times) if self.profile else None)
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
+        if after_queue is not None:
+            after_queue(self)
         if host_overlap is not None:
             host_overlap()
         # state, log-likelihood and flags back (waits for the stream)
-        a_i = np.empty((nloc, N), dtype=np.int32)
-        W_new = np.empty((nloc, N, B))
-        b_new = np.empty(nloc)
+        a_i = np.empty((nloc, N), dtype=np.int32) if readback else None
+        W_new = np.empty((nloc, N, B)) if readback else None
+        b_new = np.empty(nloc) if readback else None
         ll = np.empty(nloc)
         status = np.empty(nloc, dtype=np.int32)
-        call("pgl_get_state", ctypes.byref(sw), a_i.ctypes.data, W_new.ctypes.data, b_new.ctypes.data, ll.ctypes.data, status.ctypes.data, st)
+        call("pgl_get_state", ctypes.byref(sw), a_i.ctypes.data if readback else None, W_new.ctypes.data if readback else None,
+             b_new.ctypes.data if readback else None, ll.ctypes.data, status.ctypes.data, st)
         del keep
         if status.any():
             bad = np.nonzero(status)[0]
             raise np.linalg.LinAlgError("posterior system not positive definite for local neurons %s (flags %s)"
                                         % (bad[:8].tolist(), status[bad[:8]].tolist()))
-        return a_i.astype(bool), W_new, b_new, self._ll_host_np(ll)
+        return (a_i.astype(bool) if readback else None), W_new, b_new, self._ll_host_np(ll)
+
+    @_on_device
+    def packed_state(self):
+        """the shard's chain state as the sweep left it on the device, one row of bytes per neuron: W | b | eta (0) | a (models.state_row_layout)
+        -- what a rank contributes to the per-sweep all_gather.  Queued on the current stream (behind the sweep)."""
+        from .models import state_row_layout
+        ob, oe, oa, rb = state_row_layout(self.N, self.B)
+        nl = self.nloc
+        p = torch.zeros((nl, rb), dtype=torch.uint8, device=self.dev)
+        p[:, :ob] = self.W_dev.view(torch.uint8).view(nl, ob)
+        p[:, ob:oe] = self.b_dev.view(torch.uint8).view(nl, 8)
+        p[:, oa:oa + self.N] = self.a_dev.to(torch.uint8)
+        return p
 
     def _gram(self, s, nbb, slot):
         """omega-weighted Gram of local neurons [s, s+nbb) into the batch's J (regression.py:251-252): the stage on its own (probes, tests;
@@ -628,7 +682,9 @@ class GibbsEngine(object):
         _, _, G, PB, R, stat, S, PAs = self._i8_scratch[:8]
         assert gz <= G
         npl = ds.planes
-        call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, ds.T, D, gz, ptr(stat[0]), ptr(stat[1]), st)
+        for c0 in range(0, gz, 8):          # (the statistics pass takes at most 8 weight columns)
+            cz = min(8, gz - c0)
+            call("pgl_i8_colstats", ptr(ds.X), Dp, ctypes.c_void_p(om.value + 8 * c0), ldo, ds.T, D, cz, ptr(stat[0][c0:]), ptr(stat[1][c0:]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
         if not S and ds.PA is not None:
             call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)

@@ -5,7 +5,8 @@ looped over in Python (models.py:169-171) but sent through the HIP kernels in ba
 shard by postsynaptic neuron over the ranks of a torch.distributed process group (one process per GPU):
 
     rank r owns neurons [r*N/G, (r+1)*N/G)   -- its Y columns, its rows of (A, W, b); X is replicated.
-    per sweep:  all_gather of the shard's (a, W, b) rows (the network prior needs the full (A, W), models.py:230)
+    per sweep:  ONE all_gather_into_tensor of the shard's packed rows (W | b | eta | a as bytes), taken from the device buffers the
+                sweep updated and launched behind it on the stream (the network prior needs the full (A, W), models.py:230);
                 all_reduce of one fp64 scalar in log_likelihood().
 Random inputs are keyed by (seed, sweep, global neuron), so results do not depend on the number of ranks.
 """
@@ -25,6 +26,13 @@ def _dist():
     except ImportError:
         pass
     return None
+
+
+def state_row_layout(N, B):
+    """byte layout of one neuron's row of the packed state the ranks exchange: W (N*B doubles) | b (1 double) | eta (1 double: noise variance,
+    Gaussian model; 0 otherwise) | a (N bytes, padded to a multiple of 8)  ->  (offset of b, of eta, of a, bytes per row)"""
+    D = N * B
+    return 8 * D, 8 * D + 8, 8 * D + 16, 8 * D + 16 + -(-N // 8) * 8
 
 
 def shard_bounds(N, world, rank):
@@ -75,6 +83,7 @@ class NonlinearAutoregressiveModel(object):
             self.seed = int(t.item())
         self.sweeps_done = 0
         self.comm_seconds = 0.0        # wall time this rank has spent inside collectives (all_gather of rows, scalar all_reduce)
+        self.collectives = 0           # collectives issued by this rank (one per sweep + one per log_likelihood())
 
     def _comm_dev(self):
         """device the RCCL collectives of this rank stage through: the shard's GPU"""
@@ -166,7 +175,66 @@ class NonlinearAutoregressiveModel(object):
         if was_bool:
             out = out.astype(bool)
         self.comm_seconds += time.perf_counter() - t0
+        self.collectives += 1
         return out
+
+    # ---- the per-sweep exchange: one packed all_gather
+    def _pack_rows_host(self, a, W, b, eta=None):
+        """host (a, W, b[, eta]) of the local rows -> packed uint8 rows (state_row_layout)"""
+        ob, oe, oa, rb = state_row_layout(self.N, self.B)
+        nl = a.shape[0]
+        buf = np.zeros((nl, rb), dtype=np.uint8)
+        buf[:, :ob] = np.ascontiguousarray(W, dtype=np.float64).reshape(nl, -1).view(np.uint8)
+        buf[:, ob:oe] = np.ascontiguousarray(b, dtype=np.float64).reshape(nl, 1).view(np.uint8)
+        if eta is not None:
+            buf[:, oe:oa] = np.ascontiguousarray(eta, dtype=np.float64).reshape(nl, 1).view(np.uint8)
+        buf[:, oa:oa + self.N] = np.asarray(a).astype(np.uint8)
+        return buf
+
+    def _unpack_rows(self, buf):
+        ob, oe, oa, rb = state_row_layout(self.N, self.B)
+        n = buf.shape[0]
+        W = np.ascontiguousarray(buf[:, :ob]).view(np.float64).reshape(n, self.N, self.B)
+        b = np.ascontiguousarray(buf[:, ob:oe]).view(np.float64).reshape(n)
+        eta = np.ascontiguousarray(buf[:, oe:oa]).view(np.float64).reshape(n)
+        a = buf[:, oa:oa + self.N].astype(bool)
+        return a, W, b, eta
+
+    def _gather_start(self, packed):
+        """packed: torch uint8 (local rows, row bytes), on the shard's GPU or on the host.  Starts ONE all_gather_into_tensor of it (ranks
+        may own different counts: rows are padded to the largest shard) and returns a handle for _gather_finish.  RCCL takes the device
+        tensor as it is -- the collective is queued behind whatever the current stream still has to do --, gloo a host copy."""
+        import time
+        import torch
+        dist = _dist()
+        t0 = time.perf_counter()
+        nccl = dist.get_backend() == "nccl"
+        counts = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
+        maxc = max(hi - lo for lo, hi in counts)
+        if nccl and not packed.is_cuda:
+            packed = packed.to(self._comm_dev())
+        elif not nccl and packed.is_cuda:
+            packed = packed.cpu()
+        if packed.shape[0] < maxc:
+            pad = torch.zeros((maxc, packed.shape[1]), dtype=torch.uint8, device=packed.device)
+            pad[:packed.shape[0]] = packed
+            packed = pad
+        out = torch.empty((self.world * maxc, packed.shape[1]), dtype=torch.uint8, device=packed.device)
+        work = dist.all_gather_into_tensor(out, packed.contiguous(), async_op=True)
+        self.comm_seconds += time.perf_counter() - t0
+        self.collectives += 1
+        return work, out, counts, maxc, packed
+
+    def _gather_finish(self, handle):
+        """-> (A, W, b, eta) of ALL neurons as host arrays"""
+        import time
+        t0 = time.perf_counter()
+        work, out, counts, maxc, _keep = handle
+        work.wait()
+        host = out.cpu().numpy()
+        rows = np.concatenate([host[r * maxc: r * maxc + (hi - lo)] for r, (lo, hi) in enumerate(counts)], axis=0)
+        self.comm_seconds += time.perf_counter() - t0
+        return self._unpack_rows(rows)
 
     def log_likelihood(self, datas=None):
         """(models.py:82-96) sum over datasets and neurons; `datas` other than the stored data is evaluated through a
@@ -190,6 +258,7 @@ class NonlinearAutoregressiveModel(object):
             dist.all_reduce(t)            # the only collective on the likelihood path: one fp64 scalar
             ll = float(t.item())
             self.comm_seconds += time.perf_counter() - t0
+            self.collectives += 1
         return ll
 
     def _heldout_engine(self, datas):
@@ -290,7 +359,8 @@ class NonlinearAutoregressiveModel(object):
         return a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z
 
     def resample_regressions(self):
-        """(models.py:169-171) all local neurons through the GPU engine, then an all_gather of the new rows."""
+        """(models.py:169-171) all local neurons through the GPU engine, then ONE all_gather of the new rows (packed on the device and
+        launched behind the sweep on its stream; the host draws the next sweep's random inputs meanwhile)."""
         from .engine import make_draws
         regs = self.regressions[self.n0:self.n1]
         a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z = self._sweep_inputs()
@@ -303,7 +373,18 @@ class NonlinearAutoregressiveModel(object):
         if gaussian:
             self.engine.set_noise([r.eta for r in regs])
         kw = dict(host_overlap=draw_ahead) if self.N * self.N * self.B >= self.DRAW_AHEAD_MIN_SIZE else {}
+        exchange = _dist() is not None and not self._shard_override
+        handle = []
+        if exchange and not gaussian and hasattr(self.engine, "packed_state"):
+            # the shard's new rows never visit the host on their own: packed from the sweep's device buffers, gathered, read back once
+            kw.update(after_queue=lambda eng: handle.append(self._gather_start(eng.packed_state())), readback=False)
         a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done, **kw)
+        if handle:
+            self.sweeps_done += 1
+            A_all, W_all, b_all, _ = self._gather_finish(handle[0])
+            for n, r in enumerate(self.regressions):
+                r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
+            return
         if gaussian:
             # noise variances (regression.py:433-445): residual sums of squares under the NEW weights from the device, gamma draws
             # keyed by the global neuron index
@@ -314,7 +395,6 @@ class NonlinearAutoregressiveModel(object):
             for i, r in enumerate(regs):
                 alpha, beta = r.eta_posterior(T_total, sse[i])
                 eta[i] = 1.0 / (make_gamma_draws(self.seed, self.sweeps_done, [self.n0 + i], alpha)[0] * (1.0 / beta))
-            eta_all = eta if self._shard_override else self._gather_rows(eta)
         self.sweeps_done += 1
         if self._shard_override:
             for i, r in enumerate(regs):
@@ -322,9 +402,12 @@ class NonlinearAutoregressiveModel(object):
                 if gaussian:
                     r.eta = float(eta[i])
             return
-        A_all = self._gather_rows(a)
-        W_all = self._gather_rows(W)
-        b_all = self._gather_rows(b)
+        if not exchange:
+            A_all, W_all, b_all, eta_all = a, W, b, (eta if gaussian else None)
+        else:
+            import torch
+            packed = torch.from_numpy(self._pack_rows_host(a, W, b, eta if gaussian else None))
+            A_all, W_all, b_all, eta_all = self._gather_finish(self._gather_start(packed))
         for n, r in enumerate(self.regressions):
             r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
             if gaussian:

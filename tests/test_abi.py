@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(lib, s), "libpyglm_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == declared_symbols()      # the ctypes table mirrors the header 1:1
-    assert _lib.load().pgl_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.load().pgl_abi_version() == _lib.ABI_VERSION == 8
     assert _lib.load().pgl_flip_kmax() == 512 and _lib.load().pgl_flip_window_blocks(5) == 64
     # host-side constants of the integer Gram: bits of the column norms per number of moduli, fewest moduli at the fp64 level
     lib = _lib.load()
@@ -50,6 +50,22 @@ def test_struct_layouts_match_header_field_order():
             for part in decl.split(","):
                 names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", re.sub(r"\[[^\]]*\]", "", part).strip())[0])
         assert names == [f[0] for f in cls._fields_], (cname, names)
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """tuning knobs live behind -DPGL_AB (`make -C pyglm_amd/csrc ab`), which the package never loads: no getenv in the product sources outside
+    that fence, and none imported by the shipped library"""
+    import subprocess
+    from pyglm_amd import _lib
+    src = os.path.join(ROOT, "pyglm_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(src, f)).read()
+            text = re.sub(r"#ifdef PGL_AB\n.*?#else", "", text, flags=re.S)
+            assert "getenv" not in text, f
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert "getenv" not in nm.stdout
 
 
 def test_no_gpu_means_loud_failure():

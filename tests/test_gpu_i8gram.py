@@ -353,8 +353,8 @@ def test_sweep_with_integer_gram_equals_fp64_sweep_and_oracle(N, B, T, batch):
         np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
-def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
+@pytest.mark.parametrize("resident", [True, False])
+def test_time_slices_add_up_to_the_same_bits(resident):
     """BASELINE configs[4] cannot hold a neuron's planes at once: the integer Gram then runs in time slices whose products add up in the
     residues (pgl_i8_gram_slice), with X's planes either resident or converted per slice.  The arithmetic is exact, so J and the whole
     sweep must come out bit for bit as without slices -- including a last slice that is shorter and not a multiple of 64."""
@@ -371,20 +371,11 @@ def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
     rho = np.full((N, N), 0.5)
     perm, u, z = make_draws(5, 0, range(N), N, D)
     res = []
-    for slc in (None, "0", "640", "1024"):          # "0": one slice, but X's planes (resident = "0") converted per group instead of kept
-        if slc is None:
-            monkeypatch.delenv("PGL_I8_SLICE", raising=False)
-            monkeypatch.delenv("PGL_I8_RESIDENT", raising=False)
-        else:
-            if slc == "0":
-                monkeypatch.delenv("PGL_I8_SLICE", raising=False)
-                slc = None if resident == "1" else "0"
-            else:
-                monkeypatch.setenv("PGL_I8_SLICE", slc)
-            monkeypatch.setenv("PGL_I8_RESIDENT", resident)
-        eng = GibbsEngine(N, B, gram="int8", batch=N)
+    for slc in (None, 0, 640, 1024):          # 0: one slice, but X's planes (resident = False) converted per group instead of kept
+        kw = {} if slc is None else dict(i8_slice=slc or None, i8_resident=resident)
+        eng = GibbsEngine(N, B, gram="int8", batch=N, **kw)
         ds = eng.add_data(Y, X=X)
-        assert ds.int8 and (eng._i8_scratch[6] == (int(slc) if slc else 0)) and ((ds.PA is None) == (slc is not None and resident == "0"))
+        assert ds.int8 and (eng._i8_scratch[6] == (slc or 0)) and ((ds.PA is None) == (slc is not None and not resident))
         assert (eng._i8_scratch[7] is not None) == (ds.PA is None)
         out = eng.sweep(a, W, b, rho, *hyp, perm, u, z, seed=5, sweep=0)
         res.append((eng.Jbuf[:, :D + 2, :D + 2].cpu().numpy().copy(), out))
@@ -393,6 +384,80 @@ def test_time_slices_add_up_to_the_same_bits(monkeypatch, resident):
         np.testing.assert_array_equal(np.tril(J), np.tril(res[0][0]))
         for x, y in zip(out, res[0][1]):
             np.testing.assert_array_equal(x, y)
+
+
+def _sweep_problem(N, B, T, seed):
+    from pyglm_amd.engine import make_draws, prior_terms
+    rng = np.random.default_rng(seed)
+    D = N * B
+    Y = (rng.random((T, N)) < 0.1).astype(float)
+    X = rng.random((T, N, B)) * (rng.random((T, N, B)) < 0.3) * 0.2
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
+    b = np.full(N, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * 4.0, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+    return Y, X, (a, W, b, np.full((N, N), 0.5)) + hyp + make_draws(5, 0, range(N), N, D)
+
+
+@pytest.mark.parametrize("N,B,T", [(70, 5, 2300), (150, 5, 2100)])
+def test_group_sizes_give_the_same_bits(N, B, T):
+    """Where a plane has only a few tiles the product kernel takes more than 8 neurons per launch (16 .. 64: per-XCD lists of several neurons,
+    the last plane of each in K quarters; BASELINE configs[1] runs 64).  Exact integer arithmetic: J and the whole sweep must not depend on
+    the group size -- multiples of 8, a ragged last group (flat work list), a group that is no multiple of 8."""
+    from pyglm_amd.engine import GibbsEngine
+    Y, X, args = _sweep_problem(N, B, T, seed=13)
+    D = N * B
+    res = []
+    for G in (8, 16, 32, 64, 5):
+        eng = GibbsEngine(N, B, gram="int8", batch=N, i8_group=G)
+        ds = eng.add_data(Y, X=X)
+        assert ds.int8 and eng._i8_scratch[2] == G and (eng._i8_scratch[8] is not None) == (G % 8 == 0)
+        out = eng.sweep(*args, seed=5, sweep=0)
+        res.append((eng.Jbuf[:, :D + 2, :D + 2].cpu().numpy().copy(), out))
+        del eng
+    for J, out in res[1:]:
+        np.testing.assert_array_equal(np.tril(J), np.tril(res[0][0]))
+        for x, y in zip(out, res[0][1]):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_group_size_follows_the_item_count():
+    """_i8_plan: 8 neurons per launch where a plane has many tiles (one neuron per XCD), 64 where it has three (D = 640: 312 items of 8 neurons
+    would leave the second round half empty, 64 neurons run 9.75 full rounds)"""
+    from pyglm_amd.engine import GibbsEngine
+    r = GibbsEngine._i8_rounds
+    assert r(8, 136, 13) == 55.25 and r(8, 3, 13) == 2.0 and r(64, 3, 13) == 9.75 and r(32, 3, 13) == 5.0 and r(5, 3, 13) == 1.0
+    rng = np.random.default_rng(0)
+    for N, B, want in [(128, 5, 64), (420, 5, 8)]:
+        T = 17000
+        eng = GibbsEngine(N, B)
+        ds = eng.add_data((rng.random((T, N)) < 0.1).astype(float), X=rng.random((T, N, B)) * 0.1)
+        assert ds.int8 and eng._i8_scratch[2] == want, (N, eng._i8_scratch[2])
+        del eng
+
+
+def test_data_sets_planned_with_different_slicing_share_the_shorter_slice():
+    """one slice length per engine (pgl_sweep_t.i8_slice): a second data set whose planes only fit in slices makes the first one run in
+    slices too (and the other way round a data set no longer than the slice runs whole) -- slices add up exactly, so nothing changes in
+    the result.  (This combination used to raise.)"""
+    from pyglm_amd.engine import GibbsEngine
+    N, B, T = 70, 5, 2300
+    D = N * B
+    Y, X, args = _sweep_problem(N, B, T, seed=17)
+    res = []
+    for second_slice in (None, 640):
+        eng = GibbsEngine(N, B, gram="int8", batch=N)
+        d0 = eng.add_data(Y[:1500], X=X[:1500])
+        assert d0.int8 and eng._i8_scratch[6] == 0
+        eng._i8_over["slice"] = second_slice             # the second data set is planned as if its planes only fitted 640 bins at a time
+        d1 = eng.add_data(Y[1500:], X=X[1500:])
+        assert d1.int8 and eng._i8_scratch[6] == (second_slice or 0)
+        out = eng.sweep(*args, seed=5, sweep=0)
+        res.append((eng.Jbuf[:, :D + 2, :D + 2].cpu().numpy().copy(), out))
+        del eng
+    np.testing.assert_array_equal(np.tril(res[0][0]), np.tril(res[1][0]))
+    for x, y in zip(res[0][1], res[1][1]):
+        np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize("N,B,T,batch", [(70, 5, 2300, 70), (70, 5, 9000, 22), (33, 4, 2500, 7)])

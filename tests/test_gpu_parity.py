@@ -74,7 +74,7 @@ def _device_pg(b, z, n, seed, stream):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("b", [1.0, 2.0, 7.0, 50.0, 0.3, 2.5, 13.7])
+@pytest.mark.parametrize("b", [1.0, 2.0, 7.0, 50.0, 0.3, 2.5, 13.7, 70.5])
 def test_device_pg_analytic_checks(torch_dev, b):
     """the DEVICE sampler against known answers, not against its twin in the oracle: mean, variance and the Laplace transform
     E exp(-t w) = (cosh(z/2) / cosh(sqrt((z^2/2 + t)/2)))^b over z in {0, 0.3, 2, 6, 20, 40}, integer and real shapes b"""
@@ -105,7 +105,8 @@ def test_device_pg_ks_against_gamma_series(torch_dev, b, z):
 @pytest.mark.parametrize("b", [13.7, 50.0, 170.0])
 @pytest.mark.parametrize("z", [0.0, 2.0, 20.0])
 def test_device_pg_series_branch_on_two_million_draws(torch_dev, b, z):
-    """the series branch of the device sampler (every b > 12, every fractional shape: 32 terms + a moment-matched gamma remainder) at
+    """the series branch of the device sampler (every b > 64, every fractional part: 32 terms + a moment-matched gamma remainder; 13.7 is 13
+    exact draws + the series for 0.7, 50 is exact, 170 the series alone) at
     n = 2e6 per case: mean, variance and THIRD cumulant against the exact values of the defining series (each within 5 standard errors
     of the sample statistic), and a two-sample Kolmogorov-Smirnov test against an independent sampler of the same series -- 2000 terms,
     gamma variates from torch's generator on the GPU (n = 1e6).  tests/test_oracle_pg.py bounds analytically what the truncation changes
@@ -144,7 +145,7 @@ def test_device_pg_real_shapes_match_oracle(torch_dev):
     rng = np.random.default_rng(4)
     z = rng.standard_normal(n) * 4.0
     b = np.where(rng.random(n) < 0.5, rng.random(n) * 3.0, rng.random(n) * 40.0)
-    b[:4] = [0.0, 1e-3, 12.0, 12.000001]
+    b[:8] = [0.0, 1e-3, 12.0, 12.000001, 64.0, 64.000001, 63.5, 170.25]      # incl. both sides of the exact-sum limit
     zd, bd = torch.from_numpy(z).cuda(), torch.from_numpy(b).cuda()
     out = torch.zeros(n, dtype=torch.float64, device="cuda:0")
     call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, 9, orc.stream_id(2, 3), 5, None)
@@ -153,6 +154,30 @@ def test_device_pg_real_shapes_match_oracle(torch_dev):
     assert got[0] == 0.0 and np.all(np.isfinite(got)) and np.all(got[1:] > 0)
     close = np.abs(got - want) <= 1e-8 * np.abs(want) + 1e-300
     assert close.mean() >= 1 - 2e-3, "only %.6f of draws agree" % close.mean()
+
+
+@pytest.mark.parametrize("b", [13.0, 50.0, 64.0])
+def test_device_pg_integer_shapes_are_exact_sums(torch_dev, b):
+    """integer shapes up to 64 (negative-binomial counts y + xi) are floor(b) EXACT Devroye draws of PG(1, z) on the shared stream -- no
+    series, no approximation (pypolyagamma's samplers are exact rejection samplers too, regression.py:501-508): device = oracle at 1e-12.
+    A draw is b accept/reject chains, so the knife-edge allowance of the PG(1) test scales with b."""
+    torch = torch_dev
+    from pyglm_amd._lib import call, ptr
+    n = 40000
+    rng = np.random.default_rng(int(b))
+    z = rng.standard_normal(n) * 3.0
+    zd = torch.from_numpy(z).cuda()
+    bd = torch.full((n,), b, dtype=torch.float64, device="cuda:0")
+    out = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, 3, orc.stream_id(4, 1), 2, None)
+    got = out.cpu().numpy()
+    want = orc.pg_draw(np.full(n, b), z, 3, orc.stream_id(4, 1), 2)
+    close = np.abs(got - want) <= 1e-12 * np.abs(want)
+    assert close.mean() >= 1 - 1e-4 * b, "only %.6f of draws agree" % close.mean()
+    from tests.test_oracle_pg import pg_mean, pg_var
+    om = _device_pg(b, 2.0, 200000, 29, orc.stream_id(int(b), 7))
+    assert abs(om.mean() - pg_mean(b, 2.0)) < 5 * np.sqrt(pg_var(b, 2.0) / om.size)
+    assert abs(om.var() - pg_var(b, 2.0)) < 0.03 * pg_var(b, 2.0)
 
 
 def test_pg_moments_at_scale(torch_dev):
@@ -623,47 +648,32 @@ def test_prefix_run_equals_the_same_neurons_of_a_full_sweep(torch_dev, gram):
         np.testing.assert_array_equal(part[3][:k], full[3][:k])
 
 
-_PAIR_SCRIPT = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1])
-from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
-N, B, T = 200, 5, 1500
-D = N * B
-rng = np.random.default_rng(4)
-Y = (rng.random((T, N)) < 0.1).astype(float)
-X = rng.random((T, N, B)) * (rng.random((T, N, B)) < 0.3) * 0.3
-a = rng.random((N, N)) < 0.5
-W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
-b = np.full(N, -2.0)
-out = {}
-for tag, S in (("few", 4.0), ("many", 0.02)):          # a loose slab: few flips per window; a tight one: most blocks flip (first panels too long to pair)
-    hyp = prior_terms(np.tile(np.eye(B) * S, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev):
+    """pgl_k_flip_apply_pair stacks the panels of two proposal windows and passes over the trailing tableau once: every entry must see the same
+    multiply-adds in the same order as with a pass per window (pgl_sweep_t.flip_single_pass = 1).  N = 200: four windows (64, 64, 64, 8
+    blocks), one batch ragged."""
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    N, B, T = 200, 5, 1500
+    D = N * B
+    rng = np.random.default_rng(4)
+    Y = (rng.random((T, N)) < 0.1).astype(float)
+    X = rng.random((T, N, B)) * (rng.random((T, N, B)) < 0.3) * 0.3
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.1 * a[:, :, None]
+    b = np.full(N, -2.0)
     eng = GibbsEngine(N, B, gram="fp64", batch=64)
     eng.keep_logodds = True
     eng.add_data(Y, X=X)
     perm, u, z = make_draws(9, 0, range(N), N, D)
-    a1, W1, b1, ll = eng.sweep(a, W, b, np.full((N, N), 0.5), *hyp, perm, u, z, seed=9, sweep=0)
-    out.update({tag + "_a": a1, tag + "_W": W1, tag + "_b": b1, tag + "_lo": eng.logodds.cpu().numpy()})
-    del eng
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev, tmp_path):
-    """pgl_k_flip_apply_pair stacks the panels of two proposal windows and passes over the trailing tableau once: every entry must see the same
-    multiply-adds in the same order as with a pass per window (PGL_FLIP_PAIR=0, a switch read once per process: two child processes).
-    N = 200: four windows (64, 64, 64, 8 blocks), one batch ragged."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for v in ("1", "0"):
-        out = str(tmp_path / ("pair%s.npz" % v))
-        env = dict(os.environ, PGL_FLIP_PAIR=v)
-        p = subprocess.run([sys.executable, "-c", _PAIR_SCRIPT, root, out], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        res.append(dict(np.load(out)))
+    for single in (False, True):
+        eng.flip_single_pass = single
+        out = {}
+        for tag, S in (("few", 4.0), ("many", 0.02)):      # a loose slab: few flips per window; a tight one: most blocks flip (first panels too long to pair)
+            hyp = prior_terms(np.tile(np.eye(B) * S, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+            a1, W1, b1, ll = eng.sweep(a, W, b, np.full((N, N), 0.5), *hyp, perm, u, z, seed=9, sweep=0)
+            out.update({tag + "_a": a1, tag + "_W": W1, tag + "_b": b1, tag + "_lo": eng.logodds.cpu().numpy()})
+        res.append(out)
     assert set(res[0]) == set(res[1])
     for k in res[0]:
         np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)

@@ -111,14 +111,14 @@ def gamma_series_sample(b, z, n, rng, K=600):
     return out / (2 * np.pi ** 2)
 
 
-REAL_B = [0.3, 1.0, 2.0, 2.5, 7.0, 12.0, 13.7, 50.0]
+REAL_B = [0.3, 1.0, 2.0, 2.5, 7.0, 12.0, 13.7, 50.0, 70.5]
 Z_GRID = [0.0, 0.3, 2.0, 6.0, 20.0, 40.0]
 
 
 @pytest.mark.parametrize("b", REAL_B)
 def test_pg_real_shape_moments_and_laplace(b):
     """PG(b, z) for real-valued b (regression.py:479-489 hands real shapes to pgdrawvpar): mean, variance and the Laplace transform at
-    two arguments, over z from 0 to 40, for shapes on every branch (series only, Devroye only, Devroye + series, series for b > 12)"""
+    two arguments, over z from 0 to 40, for shapes on every branch (series only, exact Devroye sums only, Devroye + series for the fractional part; b > 64 -- the series alone -- in the cumulant tests below)"""
     n = 120000
     for iz, z in enumerate(Z_GRID):
         om = orc.pg_draw(np.full(n, b), np.full(n, z), seed=31, stream=orc.stream_id(iz, int(b * 10)))
