@@ -9,7 +9,9 @@ touched a GPU; under `python -m torch.distributed.run --nproc-per-node N bench.p
 
 One JSON line on rank 0 (contract in the task statement): `value` = sweeps/s of the WHOLE model (max over ranks of the timed region),
 `roofline` for the dominant kernel (the integer-MFMA Gram) from HIP events recorded on the launch stream, `hbm_stage` for the streaming
-kernel next to it (residue-plane conversion), `per_rank` timings incl. the time inside collectives and the host-only share,
+kernel next to it (residue-plane conversion), `per_rank` timings incl. the time inside collectives and the host-only share, `collective` =
+backend, world size and every rank's device, `fixed_state` = the stage table of a sweep from a fixed synthetic chain state (what rounds and
+boxes are compared through: `value` follows a chain that is still thinning out),
 `int8_vs_fp64` = one sweep from the same state on both Gram paths, `fp64_gram_path` = the same sampler with the Gram on the fp64 kernel,
 `cpu_baseline` = the oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -110,16 +112,25 @@ class PowerWatch(object):
     """samples the GPU's graphics clock and socket power (amdsmi, 5 Hz, ~0.5 ms per sample, on a host thread) while a region runs, so that
     the bench line itself says at which clock and power the roofline number was measured"""
 
-    def __init__(self, period=0.2):
-        self.period, self.samples, self._stop, self._thread, self.err = period, [], False, None, None
+    def __init__(self, pci_bus_id=None, period=0.2):
+        """pci_bus_id: PCI address of the GPU being timed (torch.cuda.get_device_properties(i).pci_bus_id etc.): amdsmi enumerates the
+        physical devices, the HIP index counts the visible ones -- the handle is matched by address, and the address goes into the record"""
+        self.period, self.samples, self._stop, self._thread, self.err, self.bdf = period, [], False, None, None, None
         try:
             import amdsmi
             amdsmi.amdsmi_init()
             hs = amdsmi.amdsmi_get_processor_handles()
-            want = os.environ.get("PGL_BENCH_DEVICE") or os.environ.get("LOCAL_RANK") or "0"
-            self._h = hs[int(want)] if int(want) < len(hs) else hs[0]
+            self._h = None
+            for h in hs:
+                bdf = str(amdsmi.amdsmi_get_gpu_device_bdf(h)).lower()
+                if pci_bus_id and bdf == pci_bus_id.lower():
+                    self._h, self.bdf = h, bdf
+            if self._h is None:
+                if len(hs) != 1:
+                    raise RuntimeError("no amdsmi device with PCI address %r among %d" % (pci_bus_id, len(hs)))
+                self._h, self.bdf = hs[0], str(amdsmi.amdsmi_get_gpu_device_bdf(hs[0])).lower()
             self._smi = amdsmi
-        except Exception as e:          # no amdsmi / no permission: the line then simply carries no clock record
+        except Exception as e:          # no amdsmi / no permission / no match: the line then simply carries no clock record
             self._smi, self.err = None, repr(e)
 
     def _loop(self):
@@ -152,7 +163,7 @@ class PowerWatch(object):
             return {"available": False, "error": self.err}
         w = np.array([x[1] for x in self.samples])
         c = np.array([x[2] for x in self.samples])
-        return {"available": True, "samples": len(w), "period_s": self.period, "sclk_mhz_mean": float(c.mean()), "sclk_mhz_min": float(c.min()),
+        return {"available": True, "pci_bdf": self.bdf, "samples": len(w), "period_s": self.period, "sclk_mhz_mean": float(c.mean()), "sclk_mhz_min": float(c.min()),
                 "sclk_mhz_max": float(c.max()), "power_w_mean": float(w.mean()), "power_w_max": float(w.max()),
                 "source": "amdsmi (amdsmi_get_clock_info GFX, amdsmi_get_power_info current_socket_power) sampled over the timed region"}
 
@@ -203,8 +214,6 @@ def self_launch(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        if os.environ.get("PGL_BENCH_DEVICE"):
-            env.setdefault("PGL_DEVICE_SHARE", str(n))     # ranks sharing one GPU (test hook): each engine budgets 1/n of its memory
         # the host side of a rank (NumPy / BLAS for the priors and the random inputs) must not claim every core of the node n times over
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -246,6 +255,8 @@ def main():
     ap.add_argument("--neurons", type=int, default=None,
                     help="time only the first k neurons of this rank's shard (a config whose shard is hours of work per sweep: cfg5); the line is "
                          "then seconds per neuron, labelled extrapolated")
+    ap.add_argument("--no-fixed-state", action="store_true",
+                    help="skip fixed_state (two sweeps from a fixed synthetic chain state, one fully instrumented: the table rounds are compared through)")
     ap.add_argument("--no-scaling-proxy", action="store_true",
                     help="skip scaling_proxy (one rank's shard of a 2 / 4 / 8-GPU run, timed on this GPU; N = 1 only)")
     args = ap.parse_args()
@@ -299,6 +310,8 @@ def main():
     basis, Y = synth(N, B, T, L)
     t_setup = time.perf_counter()
     ekw = {}
+    if os.environ.get("PGL_BENCH_DEVICE") and world > 1:
+        ekw["device_share"] = world                # ranks sharing one GPU (test hook): each engine budgets 1/world of its memory
     if args.batch:
         ekw["batch"] = args.batch
     if args.gram != "auto":
@@ -329,7 +342,18 @@ def main():
     t_setup = time.perf_counter() - t_setup
     eng = model.engine
 
-    watch = PowerWatch() if rank == 0 else None
+    props = torch.cuda.get_device_properties(local)
+    pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+    watch = PowerWatch(pci) if rank == 0 else None
+    # who took part in the collectives: backend, world size and every rank's device (what a multi-GPU record is checked against)
+    me = {"rank": rank, "device": "cuda:%d" % local, "name": props.name, "pci": pci}
+    ranks_info = [me]
+    if use_dist:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    collective = {"backend": (dist.get_backend() if use_dist else None), "world": world if use_dist else 1, "devices": ranks_info,
+                  "per_sweep": "one all_gather_into_tensor of the shard's packed rows (W | b | eta | a bytes: %d B per neuron) + none on the data path; "
+                               "log_likelihood(): one fp64 scalar all_reduce" % (8 * N * B + 16 + -(-N // 8) * 8)}
 
     # (sweeps of a second or more: ~550 event pairs are noise; configs[0] / configs[1] -- 3 / 50 ms per sweep -- keep the dominant kernel's only)
     timed_stages = TIMED_STAGES if float(N) * N * B * T >= 1e11 else TIMED_STAGES_SMALL
@@ -354,17 +378,14 @@ def main():
         eng.profile = False
         return allmax(mine), mine, st, model.comm_seconds - c0, pw
 
+    state0 = model.get_state() if not args.no_fixed_state else None      # the chain before its first sweep (network prior, hyper-parameters)
     for _ in range(args.warmup):
         model.resample_model()
     dt, dt_mine, stages, comm_s, power = timed(args.steps, watched=True)
-    # the stage table: one further sweep with every stage timed (not part of `value`)
-    dt_prof, _, stages_all, _, _ = timed(1, profile=True)
-    flips_prof_ms = stages_all.get("flips", {}).get("ms", 0.0)
-    for k_, v_ in stages.items():          # the top-level stages keep the numbers of the timed region
-        stages_all[k_] = dict(v_, ms=v_["ms"] / args.steps, calls=v_["calls"] / args.steps, work=v_["work"] / args.steps)
+    stages = {k_: dict(v_, ms=v_["ms"] / args.steps, calls=v_["calls"] / args.steps, work=v_["work"] / args.steps) for k_, v_ in stages.items()}
 
     # per-rank breakdown: wall time, time inside collectives, GPU time of the top-level stages, and what is left (host-only share)
-    gpu_ms = sum(v["ms"] for k, v in stages_all.items() if k in TOP_STAGES)        # per sweep (stages_all is normalised to one sweep)
+    gpu_ms = sum(v["ms"] for k, v in stages.items() if k in TOP_STAGES)            # per sweep
     mine = {"rank": rank, "neurons": model.n1 - model.n0, "ms_per_step": dt_mine / args.steps * 1e3,
             "collectives_ms_per_step": comm_s / args.steps * 1e3, "gpu_stage_ms_per_step": gpu_ms,
             "host_only_ms_per_step": max(0.0, dt_mine / args.steps * 1e3 - gpu_ms)}
@@ -375,9 +396,40 @@ def main():
 
     barrier()
     t_ll = time.perf_counter()
-    ll = model.log_likelihood()
+    ll = model.log_likelihood()                # the chain state right after the timed region (warmup + steps sweeps from the initial state)
     barrier()
     t_ll = time.perf_counter() - t_ll          # log_likelihood() on its own: activation + fused reduction (+ scalar all-reduce)
+
+    # ---- sweeps from a FIXED chain state (not part of `value`): `value` follows the chain, whose adjacency is still thinning out during the
+    # timed sweeps (the flip and weight stages follow its density), and boxes differ by a few % on the power-limited product kernel -- so rounds
+    # are compared through this table: a synthetic state (seeded: adjacency 45 % dense, small weights, the initial hyper-parameters, sweep
+    # counter 1000), swept twice from scratch: once with the top-level stage events only, once fully instrumented
+    fixed, stages_full = None, {}
+    if state0 is not None and not model._shard_override:
+        keep_state = model.get_state()
+        rs = np.random.default_rng(20240)
+        A_f = rs.random((N, N)) < 0.45
+        np.fill_diagonal(A_f, True)
+        W_f = rs.standard_normal((N, N, B)) * 0.05 * A_f[:, :, None]
+        st_f = dict(state0, sweeps_done=1000)
+        for n_, r_ in enumerate(st_f["regressions"]):
+            r_.a, r_.W, r_.b = A_f[n_].copy(), W_f[n_].copy(), np.array([-2.0])
+        model.set_state(st_f)
+        d_a, _, st_a, _, _ = timed(1)
+        dens = float(model.adjacency.mean())
+        model.set_state(st_f)
+        d_b, _, st_b, _, _ = timed(1, profile=True)
+        model.set_state(keep_state)
+        del keep_state, st_f
+        stages_full = st_b
+        fixed = {"note": "one sweep from a fixed synthetic chain state, run twice (top-level stage events only / fully instrumented); not part of "
+                         "`value`: the table rounds and boxes are compared through",
+                 "state": "adjacency ~ Bernoulli(0.45) + self-connections, W = a * N(0, 0.05^2), b = -2, initial hyper-parameters, sweep counter 1000 "
+                          "(numpy default_rng(20240))",
+                 "ms_per_step": d_a * 1e3, "ms_per_step_instrumented": d_b * 1e3, "adjacency_density_after": dens,
+                 "top_stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_a.items()},
+                 "stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_b.items()}}
+    state0 = None
 
     # ---- what ONE rank of a 2 / 4 / 8-GPU run does, timed here (the driver's multi-GPU run is the measurement; this is the stand-in a
     # one-GPU box can give): the sweep of the first N/G neurons of this model from its current state (not advanced), twice each
@@ -445,12 +497,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
                          "traffic": None, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
-            "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages_all.items()},
-            "stages_note": "ms per sweep on rank 0; %s from HIP events inside the timed region (averaged over its %d sweeps); "
-                           "%s from one further, fully instrumented sweep (%.1f ms, flips %.1f ms there; the flip stage follows the density of "
-                           "the adjacency, which still falls during the timed sweeps) that is not part of `value`"
-                           % ("the top-level stages" if timed_stages is TIMED_STAGES else ", ".join(k for k in stages), args.steps,
-                              ", ".join(k for k in stages_all if k not in stages) or "nothing", dt_prof * 1e3, flips_prof_ms),
+            "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
+            "stages_note": "ms per sweep on rank 0 from HIP events inside the timed region (%s; averaged over its %d sweeps); the pieces of the "
+                           "flip stage are in fixed_state.stages_ms (a separate, fully instrumented sweep from a fixed chain state)"
+                           % ("the top-level stages" if timed_stages is TIMED_STAGES else "the dominant kernel's only at this size", args.steps),
+            "fixed_state": fixed, "collective": collective,
             "per_rank": per_rank,
             "setup_s": round(t_setup, 2), "log_likelihood_after": ll, "log_likelihood_ms": round(t_ll * 1e3, 2),
         }
@@ -497,7 +548,7 @@ def main():
                                            "%d GPUs: %.0f s per sweep per rank by extrapolation -- neurons are independent and of equal cost, "
                                            "models.py:169-171); the network prior (host, replicated on every rank) is in the timed region once per sweep"
                                            % (k_, N // 8, 8, dt / args.steps / k_ * (N // 8))}
-        pl = stages_all.get("pg_loglik", dict(ms=0.0, work=0.0))
+        pl = stages.get("pg_loglik") or stages_full.get("pg_loglik") or dict(ms=0.0, work=0.0)
         if pl["ms"] > 0:
             out["stage_E_note"] = ("pg_loglik_kernel: %.1f M PG draws/s; bound by the sampler's transcendental VALU work (rejection loops), not by "
                                    "HBM (40 B per draw = %.2f TB/s)" % (pl["work"] / (pl["ms"] * 1e-3) * 1e-6, 40.0 * pl["work"] / (pl["ms"] * 1e-3) * 1e-12))
