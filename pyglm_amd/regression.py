@@ -67,7 +67,7 @@ class _SparseScalarRegressionBase(object):
         setattr(self, name, value)
         self._hyp_version = self._hyp_version + 1
         # an array the caller passed in and that was stored as it is (no copy) stays editable in the caller's hands
-        if isinstance(given, np.ndarray) and isinstance(value, np.ndarray) and np.shares_memory(value, given):
+        if isinstance(given, np.ndarray) and isinstance(value, np.ndarray) and np.may_share_memory(value, given):
             self._handed_out = self._handed_out | {name}
         else:
             self._handed_out = self._handed_out - {name}

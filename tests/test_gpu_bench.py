@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(gpus, *extra):
+def _bench(gpus, *extra, **envkw):
     env = dict(os.environ, PGL_BENCH_DEVICE="0", PGL_DIST_BACKEND="gloo")
+    env.update(envkw)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--config", "cfg2", "--steps", "2", "--warmup", "1",
@@ -41,3 +42,13 @@ def test_self_launch_two_ranks_equals_one_rank():
     # per-rank partial sums (one all_reduce), so it agrees to rounding of the summation order, not to the bit
     a, b = one["log_likelihood_after"], two["log_likelihood_after"]
     assert abs(a - b) <= 1e-12 * abs(a)
+    assert one["collective"]["backend"] is None and two["collective"] == dict(two["collective"], backend="gloo", world=2)
+    assert [d["rank"] for d in two["collective"]["devices"]] == [0, 1] and all(d["device"] == "cuda:0" for d in two["collective"]["devices"])
+    fs = one["fixed_state"]
+    assert fs["ms_per_step"] > 0 and fs["stages_ms"]["flips"] > 0 and 0 < fs["adjacency_density_after"] < 1
+    # bench.py over RCCL with the one rank this box has (PGL_FORCE_DIST: the process group is initialised with backend "nccl", world_size 1):
+    # the same line, the same chain, and the record of who took part
+    rccl = _bench(1, PGL_FORCE_DIST="1", PGL_DIST_BACKEND="nccl")
+    assert rccl["collective"]["backend"] == "nccl" and rccl["collective"]["world"] == 1 and len(rccl["collective"]["devices"]) == 1
+    assert rccl["log_likelihood_after"] == one["log_likelihood_after"]
+    assert rccl["per_rank"][0]["collectives_ms_per_step"] > 0

@@ -285,3 +285,80 @@ def test_cfg4_full_size_sweep_int8_equals_fp64():
     """BASELINE.json configs[3]: NegativeBinomialGLM N = 512, B = 5, T = 100 000 (PG shape b = y + xi; dense prior: rho = 1, no flips)
     on an 8-neuron shard"""
     _fullsize_sweep_checks("negbin", 512, 5, 100000, 8, rho=1.0, S_w=1.0, xi=2.0)
+
+
+def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21):
+    """Two neurons of a BASELINE.json configuration at its OWN size, one sweep through the default path (gram='auto': the integer Gram),
+    against the oracle -- the NumPy restatement of regression.py:225-262, 282-320, 323-340 on the box's host cores -- fed the GPU's own
+    omega: (i) the assembled posterior (J, h) against prior_stats + lkhd_stats, error relative to |x_i| |omega x_j|; (ii) the first `nprop`
+    collapsed-flip proposals: log-odds to 1e-9, decisions bit-equal (each costs the oracle two dense Choleskys of the ~3000-dim active
+    block, so not all 1024); (iii) the weight draw against gaussian_info_draw on the final active set."""
+    import gc
+    import torch
+    from oracle import pyglm_oracle as orc
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    gc.collect()
+    torch.cuda.empty_cache()
+    basis, Y, rng = _problem(N, B, T)
+    if obs == "negbin":
+        Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)
+    D, nloc = N * B, 2
+    a = rng.random((nloc, N)) < (1.0 if rho == 1.0 else 0.6)
+    W = rng.standard_normal((nloc, N, B)) * 0.05 * a[:, :, None]
+    b = np.full(nloc, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * S_w, (nloc, N, 1, 1)), np.zeros((nloc, N, B)), np.ones(nloc), np.full(nloc, -2.0))
+    perm, u, z = make_draws(seed, 0, range(nloc), N, D)
+    eng = GibbsEngine(N, B, 0, nloc, batch=nloc, obs=obs, xi=xi)
+    ds = eng.add_data(Y, basis=basis)
+    assert eng.gram == "auto" and ds.int8                      # the path the benchmark runs
+    eng.keep_logodds = True
+    a1, W1, b1, ll1 = eng.sweep(a, W, b, np.full((nloc, N), rho), *hyp, perm, u, z, seed=seed, sweep=0)
+    lo = eng.logodds.cpu().numpy()
+    om = ds.OK[:T, :nloc].cpu().numpy()
+    Xd = ds.X[:T, :D]
+    na = torch.sqrt((Xd * Xd).sum(0)).cpu().numpy()
+    X = Xd.cpu().numpy()
+    for i in range(nloc):
+        r = orc.Regression(N, B, rho=rho, mu_w=0.0, S_w=S_w, mu_b=-2.0, S_b=1.0, obs=obs, xi=xi)
+        r.a, r.W, r.b = a[i].copy(), W[i].copy(), b[i:i + 1].copy()
+        y = Y[:, i]
+        np.testing.assert_allclose(ll1[i], r.log_likelihood(X, y).sum(), rtol=1e-11)
+        # (i) posterior system
+        Jp0, hp0 = r.prior_stats()
+        Jl, hl = r.lkhd_stats([(X, y)], [om[:, i]])
+        Jq, hq = Jp0 + Jl, hp0 + hl
+        Jg, hg = eng.posterior(i)
+        nb_ = torch.sqrt(((ds.OK[:T, i] ** 2)[:, None] * Xd * Xd).sum(0)).cpu().numpy()
+        err = np.abs(Jg[:D, :D] - Jq[:D, :D]) / np.maximum(np.outer(na, nb_), 1e-300)
+        assert err.max() < 3e-14 and np.sqrt(np.mean(err ** 2)) < 5e-15, (err.max(), np.sqrt(np.mean(err ** 2)))   # (the oracle's own dgemm included)
+        np.testing.assert_allclose(Jg[D, :], Jq[D, :], rtol=1e-12, atol=0)         # bias row: X' omega, sum omega (+ prior)
+        np.testing.assert_allclose(hg, hq, rtol=1e-11, atol=1e-9 * np.abs(hq).max())
+        del Jl, Jg, err
+        # (ii) the first proposals of the collapsed flips
+        if rho < 1.0:
+            trace = []
+            r.collapsed_resample_a(Jp0, hp0, Jq, hq, perm[i][:nprop], u[i][:nprop], trace)
+            assert [t[0] for t in trace] == perm[i][:nprop].tolist()
+            np.testing.assert_allclose(lo[i][:nprop], [t[1] for t in trace], rtol=1e-9, atol=1e-9)
+            assert [int(a1[i][t[0]]) for t in trace] == [t[2] for t in trace]      # decisions: bit-equal
+            assert any(t[2] != int(a[i][t[0]]) for t in trace)                     # (some of them flip)
+        # (iii) the weight draw on the final active set, from the oracle's own posterior system
+        r.a = a1[i].copy()
+        r.resample_W(Jq, hq, z[i])
+        np.testing.assert_allclose(W1[i], r.W, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(b1[i], r.b[0], rtol=1e-7, atol=1e-9)
+        assert np.all(W1[i][~a1[i]] == 0)
+        del Jp0, Jq
+    del eng, ds, X, Xd
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_two_neurons_against_the_oracle_at_full_size():
+    """BASELINE.json configs[2], the metric's own configuration (SparseBernoulliGLM N = 1024, B = 5, T = 100 000)"""
+    _oracle_at_full_size("bernoulli", 1024, 5, 100000, rho=0.5, S_w=10.0)
+
+
+def test_cfg4_two_neurons_against_the_oracle_at_full_size():
+    """BASELINE.json configs[3] (NegativeBinomialGLM N = 512, B = 5, T = 100 000, xi = 2, dense prior: rho = 1 -- no flips, a 2561-dim draw)"""
+    _oracle_at_full_size("negbin", 512, 5, 100000, rho=1.0, S_w=1.0, xi=2.0)

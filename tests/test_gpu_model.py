@@ -253,7 +253,7 @@ def test_long_chain_matches_oracle_chain_statistically():
     assert np.abs(A1 - A2).max() < 0.35
 
 
-def _two_rank_worker(rank, world, port, out_path, backend="gloo"):
+def _two_rank_worker(rank, world, port, out_path, backend="gloo", force_group=False):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -267,7 +267,7 @@ def _two_rank_worker(rank, world, port, out_path, backend="gloo"):
     if backend == "nccl":                      # one GPU per rank, RCCL collectives: the production layout
         dev = "cuda:%d" % rank
         torch.cuda.set_device(rank)
-    if world > 1:
+    if world > 1 or force_group:
         kw = dict(device_id=torch.device(dev)) if backend == "nccl" else {}
         dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kw)
     np.random.seed(0)
@@ -288,9 +288,34 @@ def _two_rank_worker(rank, world, port, out_path, backend="gloo"):
         np.savez(out_path, A=model.adjacency, W=model.weights, b=model.biases, lls=np.array(lls), means=model.means[0])
     else:
         _ = model.means                       # (collective: every rank takes part in the gathers)
-    if world > 1:
+    if world > 1 or force_group:
+        assert model.collectives == 3 + 6 + 1           # one packed all_gather per sweep, one scalar all_reduce per log_likelihood(), one gather of the means
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_over_rccl_equals_no_process_group(tmp_path):
+    """the production collectives with the ranks a one-GPU box can give them: backend "nccl" (= RCCL), world_size 1.  The seed broadcast, the
+    MIN all-reduce of the integer-Gram decision, the packed all_gather_into_tensor of the shard's rows ON DEVICE buffers and the scalar
+    all-reduce of the log-likelihood all execute through RCCL; state, log-likelihoods and means must equal the run without a process group
+    bit for bit."""
+    import torch.multiprocessing as mp
+    one, rccl = str(tmp_path / "one.npz"), str(tmp_path / "rccl.npz")
+    mp.spawn(_two_rank_worker, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_two_rank_worker, args=(1, _free_port(), rccl, "nccl", True), nprocs=1, join=True)
+    a, b = np.load(one), np.load(rccl)
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 @pytest.mark.timeout(600)
