@@ -380,6 +380,7 @@ struct GramArgs {
     const int8_t* PB;                     // [G][np] planes
     int8_t* R;                            // [G][np][Dq][Dq]
     int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
+    int nkt;                              // K tiles to multiply: the time bins rounded up to 64 (<= Kp / 64: very short slices are padded to 4 tiles of zeros)
     int kt0;                              // first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
     long KpA; int ka0;                    // the X planes may be longer than this slice of the omega X planes: their bytes per row, first K tile
@@ -461,7 +462,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
     const long plane = (long)g.Dq * g.Kp;
     const int8_t* A = g.PA + (long)q * g.Dq * g.KpA + (long)g.ka0 * 1024;
     const int8_t* B = g.PB + ((long)gz * g.np + q) * plane;
-    const int nkt = (int)(g.Kp / BKB);
+    const int nkt = g.nkt;
     // DMA: per K tile 640 rows x 64 B = 40 requests of 1 KiB; wave w issues requests w, w+4, ..., w+36 (row blocks 0..19 = A, 20..39 = B).
     // A request = wave-uniform base (scalar registers) + one per-lane byte offset shared by all requests
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -882,7 +883,8 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     if (KpA <= 0) { KpA = Kp; ka0 = 0; }
-    if (KpA % BKB != 0 || (long)(ka0 + Kp / BKB) * BKB > KpA) { pgl_set_error("i8 gram: slice of %ld bytes at tile %d outside the X planes (%ld)", Kp, ka0, KpA); return PGL_ERR_ARG; }
+    const int nkt = (T + BKB - 1) / BKB;
+    if (KpA % BKB != 0 || (long)(ka0 + nkt) * BKB > KpA) { pgl_set_error("i8 gram: slice of %d tiles at tile %d outside the X planes (%ld bytes per row)", nkt, ka0, KpA); return PGL_ERR_ARG; }
     // Three LDS stages (requests one tile ahead).  A fourth stage (two tiles ahead, all 160 KiB) measured 6.7 % SLOWER on real planes (107.2 vs
     // 100.5 ms per launch of 8 neurons at cfg3): the 32 workgroups of an XCD then hold 3 x 40 KiB in flight each, which is the whole 4 MiB
     // L2, and the strips they share fall out of it.
@@ -894,9 +896,8 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
     if (total <= 0) return PGL_OK;
     if (total * 4 > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
     const unsigned grid = (unsigned)(total < n_cu ? total : n_cu);
-    const int nkt = (int)(Kp / BKB);
     for (int kt0 = 0; kt0 < nkt; kt0 += KCH) {
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr};
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, nkt, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         hipLaunchKernelGGL(i8_gram_kernel, dim3(grid), dim3(256), BNST * BSTAGE, st, g);
         PGL_CHECK_LAUNCH();

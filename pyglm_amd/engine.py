@@ -417,10 +417,15 @@ class GibbsEngine(object):
         for resident in ((True, False) if keep else (False,)):
             ok = [G for G in groups if fit(resident, G) >= kp_full]
             if ok:
-                # per-neuron cost of a launch in item-times; the smallest group within 1.5 % of the best (memory is better spent elsewhere)
+                # the largest group up to 8 that fits (one neuron per XCD), more only where the per-neuron cost of a launch (item-times) falls
+                # by 1.5 % or more with it (memory is better spent elsewhere)
                 cost = {G: self._i8_rounds(G, ntiles, planes, cus) / G for G in ok}
-                best = min(cost.values())
-                return dict(planes=planes, resident=resident, G=min(G for G in ok if cost[G] <= 1.015 * best), slice=0)
+                small = [G for G in ok if G <= 8]
+                pick = max(small) if small else min(ok)
+                for G in sorted(G for G in ok if G > 8 and G > pick):
+                    if cost[G] < 0.985 * cost[pick]:
+                        pick = G
+                return dict(planes=planes, resident=resident, G=pick, slice=0)
         cands = [(resident, G, fit(resident, G)) for resident in ((True, False) if keep else (False,)) for G in groups if G <= 8]
         cands = [c for c in cands if c[2] >= 16384]
         if not cands:
