@@ -679,3 +679,4 @@ def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev):
         np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
     flips_few = (res[0]["few_a"] != res[0]["many_a"]).sum()
     assert flips_few > 0            # (the two regimes are different chains)
+

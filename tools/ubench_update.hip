@@ -169,5 +169,22 @@ int main(int argc, char** argv) {
         snprintf(name, sizeof name, "chol trailing K=256 q0=%d (rem<=%d)", q0, rem);
         check(name, PGL_GEMM_TRI1, t, 2, fl, true);
     }
+    // ---- does the LAYOUT of C matter for the read-modify-write updates?  One tile column (5122 x 128 outputs per neuron, rank 512) with C rows
+    // 41 KB apart (the tableau's row-major layout: a 128 x 128 tile is 128 pieces of 1 KiB) against the same product with C contiguous
+    // (ldc = 128: a tile is one 128-KiB run -- what a tile-major tableau would give).  Same operands, same flops, generic kernel.
+    for (int K : {512, 256, 64}) {
+        set_i(bk, [&](int i) { return K; });
+        for (int contiguous = 0; contiguous < 2; ++contiguous) {
+            PglGemmArgs t{};
+            t.A = W; t.lda = ldj; t.strideA = (long)KMAX * ldj;
+            t.B = U; t.ldb = ldj; t.strideB = (long)KMAX * ldj;
+            t.C = C1; t.ldc = contiguous ? 128 : ldj; t.strideC = sq;
+            t.M = Md - 2; t.N = 128; t.K = KMAX; t.a_cols = ldj; t.b_cols = ldj; t.nbatch = nb;
+            t.alpha = -1.0; t.beta = 1.0; t.tri = 0; t.batch_k = bk; t.pipe = 0;
+            const double ms = time_ms(st, 5, [&] { pgl_launch_gemm(PGL_GEMM_PLAIN, t, st); });
+            printf("C layout test: 5120 x 128 strip, rank %3d, C %s: %8.3f ms (%5.1f TF)\n", K, contiguous ? "contiguous (ldc = 128)  " : "row-major (ldc = 5136)  ", ms,
+                   (double)nb * 2.0 * (Md - 2) * 128.0 * K / ms * 1e-9);
+        }
+    }
     return 0;
 }
