@@ -10,8 +10,8 @@ touched a GPU; under `python -m torch.distributed.run --nproc-per-node N bench.p
 One JSON line on rank 0 (contract in the task statement): `value` = sweeps/s of the WHOLE model (max over ranks of the timed region),
 `roofline` for the dominant kernel (the integer-MFMA Gram) from HIP events recorded on the launch stream, `hbm_stage` for the streaming
 kernel next to it (residue-plane conversion), `per_rank` timings incl. the time inside collectives and the host-only share, `collective` =
-backend, world size and every rank's device, `fixed_state` = the stage table of a sweep from a fixed synthetic chain state (what rounds and
-boxes are compared through: `value` follows a chain that is still thinning out),
+backend, world size and every rank's device, `fixed_state` = the stage table of the sweep after the timed region, run twice from the same chain
+state (`value` follows a chain that is still thinning out; this is one point of it),
 `int8_vs_fp64` = one sweep from the same state on both Gram paths, `fp64_gram_path` = the same sampler with the Gram on the fp64 kernel,
 `cpu_baseline` = the oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -256,7 +256,7 @@ def main():
                     help="time only the first k neurons of this rank's shard (a config whose shard is hours of work per sweep: cfg5); the line is "
                          "then seconds per neuron, labelled extrapolated")
     ap.add_argument("--no-fixed-state", action="store_true",
-                    help="skip fixed_state (two sweeps from a fixed synthetic chain state, one fully instrumented: the table rounds are compared through)")
+                    help="skip fixed_state (the sweep after the timed region run twice from the same chain state, once fully instrumented)")
     ap.add_argument("--no-scaling-proxy", action="store_true",
                     help="skip scaling_proxy (one rank's shard of a 2 / 4 / 8-GPU run, timed on this GPU; N = 1 only)")
     args = ap.parse_args()
@@ -378,7 +378,6 @@ def main():
         eng.profile = False
         return allmax(mine), mine, st, model.comm_seconds - c0, pw
 
-    state0 = model.get_state() if not args.no_fixed_state else None      # the chain before its first sweep (network prior, hyper-parameters)
     for _ in range(args.warmup):
         model.resample_model()
     dt, dt_mine, stages, comm_s, power = timed(args.steps, watched=True)
@@ -400,36 +399,28 @@ def main():
     barrier()
     t_ll = time.perf_counter() - t_ll          # log_likelihood() on its own: activation + fused reduction (+ scalar all-reduce)
 
-    # ---- sweeps from a FIXED chain state (not part of `value`): `value` follows the chain, whose adjacency is still thinning out during the
-    # timed sweeps (the flip and weight stages follow its density), and boxes differ by a few % on the power-limited product kernel -- so rounds
-    # are compared through this table: a synthetic state (seeded: adjacency 45 % dense, small weights, the initial hyper-parameters, sweep
-    # counter 1000), swept twice from scratch: once with the top-level stage events only, once fully instrumented
+    # ---- two more sweeps from ONE chain state (not part of `value`): the state the timed region ended in, restored in between.  `value`
+    # follows the chain, whose adjacency is still thinning out during the timed sweeps (the flip and weight stages follow its density); this
+    # table is one state swept twice -- once with the top-level stage events only, once fully instrumented (the pieces of the flip stage) --
+    # so the two agree on what they measure, and with the driver's fixed --warmup / --steps it is the same point of the same seeded chain
+    # from round to round
     fixed, stages_full = None, {}
-    if state0 is not None and not model._shard_override:
+    if not args.no_fixed_state and not model._shard_override:
         keep_state = model.get_state()
-        rs = np.random.default_rng(20240)
-        A_f = rs.random((N, N)) < 0.45
-        np.fill_diagonal(A_f, True)
-        W_f = rs.standard_normal((N, N, B)) * 0.05 * A_f[:, :, None]
-        st_f = dict(state0, sweeps_done=1000)
-        for n_, r_ in enumerate(st_f["regressions"]):
-            r_.a, r_.W, r_.b = A_f[n_].copy(), W_f[n_].copy(), np.array([-2.0])
-        model.set_state(st_f)
+        dens0 = float(model.adjacency.mean())
         d_a, _, st_a, _, _ = timed(1)
-        dens = float(model.adjacency.mean())
-        model.set_state(st_f)
+        dens1 = float(model.adjacency.mean())
+        model.set_state(keep_state)
         d_b, _, st_b, _, _ = timed(1, profile=True)
         model.set_state(keep_state)
-        del keep_state, st_f
+        del keep_state
         stages_full = st_b
-        fixed = {"note": "one sweep from a fixed synthetic chain state, run twice (top-level stage events only / fully instrumented); not part of "
-                         "`value`: the table rounds and boxes are compared through",
-                 "state": "adjacency ~ Bernoulli(0.45) + self-connections, W = a * N(0, 0.05^2), b = -2, initial hyper-parameters, sweep counter 1000 "
-                          "(numpy default_rng(20240))",
-                 "ms_per_step": d_a * 1e3, "ms_per_step_instrumented": d_b * 1e3, "adjacency_density_after": dens,
+        fixed = {"note": "the sweep after the timed region (chain sweep %d), run twice from the same state (top-level stage events only / fully "
+                         "instrumented); not part of `value`, the chain is not advanced" % (args.warmup + args.steps),
+                 "ms_per_step": d_a * 1e3, "ms_per_step_instrumented": d_b * 1e3, "adjacency_density_before": dens0, "adjacency_density_after": dens1,
                  "top_stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_a.items()},
-                 "stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_b.items()}}
-    state0 = None
+                 "stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_b.items()},
+                 "stages_ms_note": "flips.init / flips.decide / flips.apply are the pieces of `flips`"}
 
     # ---- what ONE rank of a 2 / 4 / 8-GPU run does, timed here (the driver's multi-GPU run is the measurement; this is the stand-in a
     # one-GPU box can give): the sweep of the first N/G neurons of this model from its current state (not advanced), twice each
@@ -499,7 +490,7 @@ def main():
                          "traffic": None, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
             "stages_note": "ms per sweep on rank 0 from HIP events inside the timed region (%s; averaged over its %d sweeps); the pieces of the "
-                           "flip stage are in fixed_state.stages_ms (a separate, fully instrumented sweep from a fixed chain state)"
+                           "flip stage are in fixed_state.stages_ms (the next sweep of the chain, fully instrumented, not part of `value`)"
                            % ("the top-level stages" if timed_stages is TIMED_STAGES else "the dominant kernel's only at this size", args.steps),
             "fixed_state": fixed, "collective": collective,
             "per_rank": per_rank,

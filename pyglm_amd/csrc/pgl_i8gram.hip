@@ -372,14 +372,15 @@ __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
 constexpr int BKB = 64;                                      // bytes (= time bins) per row of a K tile
 constexpr int KCH = 2000;                                    // K tiles between re-reductions: 128 + 128000 * 128 * 128 < 2^31
 constexpr int CH = 32;                               // flat work list (ragged groups): chunk per XCD
-constexpr int SB = 6;                                // clustered tile order: super-blocks of SB x SB tiles (measured on one box, ms per launch at cfg3:
-                                                     // 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
+constexpr int SB = 6;                                // clustered tile order of the flat list: super-blocks of SB x SB tiles (measured on one box, ms per
+                                                     // launch at cfg3: 4: 101.4 / 100.1, 5: 101.1, 6: 102.0 / 100.1, 8: 105.2, 16: 103.7)
 
 struct GramArgs {
     const int8_t* PA;                     // [np] planes
     const int8_t* PB;                     // [G][np] planes
     int8_t* R;                            // [G][np][Dq][Dq]
     int Dq; long Kp; int G; int np;       // np = number of moduli in use (the first np of the table)
+    int sbr, sbc;                         // super-blocks of the clustered tile order: tile rows x tile columns
     int nkt;                              // K tiles to multiply: the time bins rounded up to 64 (<= Kp / 64: very short slices are padded to 4 tiles of zeros)
     int kt0;                              // first K tile of this pass (passes of KCH tiles; later ones accumulate)
     int* sched;                           // 8 per-XCD work counters, zeroed before the launch
@@ -396,23 +397,24 @@ __device__ __forceinline__ int isqrt_tri_i(int t) {
     return r;
 }
 
-// tile t of a plane's lower triangle in CLUSTERED order: super-blocks of SB x SB tiles, row by row (boustrophedon), so that a run of
-// ~32 consecutive tiles touches few distinct 256-row strips: the workgroups of an XCD, which take such a run together, share the
-// strips through their L2 (with the plain triangular order every workgroup streamed its own two strips: 2.2 instead of 3.7 POPS)
-__device__ __forceinline__ void clustered_tile(int t, int ntm, int& tm, int& tn) {
-    const int nsb = (ntm + SB - 1) / SB;
-    for (int I = 0; I < nsb; ++I) {
-        const int r0 = I * SB, nr = min(SB, ntm - r0);
-        for (int jj = 0; jj <= I; ++jj) {
-            const int J = (I & 1) ? I - jj : jj;
-            const int c0 = J * SB, nc = min(SB, ntm - c0);
-            const int cnt = I == J ? nr * (nr + 1) / 2 : nr * nc;
-            if (t < cnt) {
-                if (I == J) { const int r = isqrt_tri_i(t); tm = r0 + r; tn = c0 + t - r * (r + 1) / 2; }
-                else { tm = r0 + t / nc; tn = c0 + t % nc; }
-                return;
+// tile t of a plane's lower triangle in CLUSTERED order: super-blocks of sbr x sbc tiles (tile rows = strips of the X planes, tile columns
+// = strips of the neuron's omega X planes), block row by block row (boustrophedon), row-major inside a block and only the tiles on or below
+// the diagonal -- so that a run of ~32 consecutive tiles touches few distinct 320-row strips: the workgroups of an XCD, which take such a
+// run together, share the strips through their L2 (with the plain triangular order every workgroup streamed its own two strips: 2.2
+// instead of 3.7 POPS)
+__device__ __forceinline__ void clustered_tile(int t, int ntm, int sbr, int sbc, int& tm, int& tn) {
+    const int nbr = (ntm + sbr - 1) / sbr;
+    for (int I = 0; I < nbr; ++I) {
+        const int r0 = I * sbr, r1 = min(ntm, r0 + sbr);              // tile rows [r0, r1)
+        const int nbc = (r1 - 1) / sbc + 1;                            // column blocks that reach the diagonal of this block row
+        for (int jj = 0; jj < nbc; ++jj) {
+            const int J = (I & 1) ? nbc - 1 - jj : jj;
+            const int c0 = J * sbc, c1 = min(ntm, c0 + sbc);
+            for (int r = max(r0, c0); r < r1; ++r) {
+                const int cnt = min(c1, r + 1) - c0;                   // tiles (r, c0 .. min(c1 - 1, r))
+                if (t < cnt) { tm = r; tn = c0 + t; return; }
+                t -= cnt;
             }
-            t -= cnt;
         }
     }
     tm = tn = 0;
@@ -602,10 +604,10 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
 // persistent: one workgroup per CU pulls (neuron of the group, plane, tile in clustered order) items from per-XCD work lists; a workgroup
 // reads the XCC it runs on and takes the next item of that XCD's list, stealing from the next XCD when its own list is exhausted.
 //   G a multiple of 8 (every full group): XCD y owns NEURONS y, y + 8, ... -- its list is, plane by plane, those neurons' tiles in order.
-//     With one neuron per XCD (G = 8: large D) the 32 workgroups of an XCD walk one 6 x 6 super-block of one plane together (they share
-//     its ~12 strips through their L2), and the eight XCDs walk the SAME plane and super-block at the same time, each for its own neuron:
-//     the X-plane strips (half of every item's operand stream, identical for all neurons) are fetched from HBM once and found in the
-//     memory-side cache by the other seven.  With several neurons per XCD (G = 16 .. 64: small D, where a plane has only a few tiles and 8
+//     With one neuron per XCD (G = 8: large D) the 32 workgroups of an XCD walk one column block of one plane together (two omega X strips
+//     of their neuron, shared through their L2, against all the X strips below the diagonal), and the eight XCDs walk the SAME plane and
+//     column block at the same time, each for its own neuron: the X-plane strips (half of every item's operand stream, identical for all
+//     neurons) are fetched from HBM once and found in the memory-side cache by the other seven.  With several neurons per XCD (G = 16 .. 64: small D, where a plane has only a few tiles and 8
 //     neurons would not fill the CUs for more than a round or two) the whole chip still walks one plane at a time.
 //   otherwise (a ragged last group): the flat item list is cut into chunks of CH, chunk c belongs to XCD c % 8.
 // Placement is used for speed only -- any placement gives the same result.
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(256) void i8_gram_kernel(GramArgs g) {
                     tile = grp * 32 + within % tg;
                     gz = y + 8 * j; q = g.np - 1;
                 }
-                clustered_tile(tile, ntm, tm, tn);
+                clustered_tile(tile, ntm, g.sbr, g.sbc, tm, tn);
                 ticket[1] = gz; ticket[2] = tm; ticket[3] = tn; ticket[4] = kpart; ticket[5] = q;
             }
             ticket[0] = w;
@@ -896,8 +898,18 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
     if (total <= 0) return PGL_OK;
     if (total * 4 > 0x7fffffffL) { pgl_set_error("i8 gram: %ld work items", total); return PGL_ERR_ARG; }
     const unsigned grid = (unsigned)(total < n_cu ? total : n_cu);
+    // Tile order.  Per-XCD lists (an XCD owns whole neurons): FULL-HEIGHT column blocks two tiles wide -- a neuron's omega X strips (the
+    // per-neuron half of the operand stream: nothing shares them but the co-walking workgroups of the XCD) are then fetched once per plane,
+    // while the X strips, which every column block walks again, are shared by all eight XCDs through the memory-side cache.  Same-box A/B at
+    // cfg3, ms per launch of 8 neurons: 6 x 6 100.3-100.6 | 8 x 4 101.5-103.7 | 4 x 8 101.1 | 3 x 12 103.5 | 12 x 3 99.2 | 16 x 4 98.9 |
+    // 16 x 3 98.7 | 16 x 2 98.2-98.6 | 16 x 1 98.5-98.9 (profiles/r04_i8_tile_order_ab.txt).  The flat list of a ragged group keeps 6 x 6.
+    // (Pacing the eight XCDs' lists to within one to three rounds of each other -- a bounded wait at item boundaries on the other lists'
+    // counters -- changed nothing: 96.9-97.1 ms without, 96.9-98.2 with, profiles/r04_i8_xcd_pacing_ab.txt: they stay together on their own.)
+    const bool lists = G % 8 == 0;
+    static const int sbr_ab = pgl_ab_int("PGL_I8_SBR", 0), sbc_ab = pgl_ab_int("PGL_I8_SBC", 0);
+    const int sbr = sbr_ab > 0 ? sbr_ab : (lists ? ntm : SB), sbc = sbc_ab > 0 ? sbc_ab : (lists ? 2 : SB);
     for (int kt0 = 0; kt0 < nkt; kt0 += KCH) {
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, nkt, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr};
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, sbr, sbc, nkt, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         hipLaunchKernelGGL(i8_gram_kernel, dim3(grid), dim3(256), BNST * BSTAGE, st, g);
         PGL_CHECK_LAUNCH();

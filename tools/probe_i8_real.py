@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Times one group launch of the integer Gram (stats / planes / product / CRT) on the bench's own data (cfg3: basis-filtered Bernoulli(0.08)
 spikes, omega ~ PG(1, psi)) -- residue planes of real data are not uniformly random bytes, and under the package power limit that
-matters.  python tools/probe_i8_real.py [planes=13] [reps=6]"""
+matters.  python tools/probe_i8_real.py [planes=13] [reps=6] [only=stage]
+PGL_PROBE_LIB=ab loads lib/libpyglm_hip_ab.so (`make -C pyglm_amd/csrc ab`), whose tuning knobs read the environment (pgl_common.h)."""
 import ctypes
 import sys
 
@@ -9,12 +10,17 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import os                                           # noqa: E402
+import pyglm_amd._lib as _l                         # noqa: E402
+if os.environ.get("PGL_PROBE_LIB") == "ab":
+    _l.LIB_PATH = _l.LIB_PATH.replace("libpyglm_hip.so", "libpyglm_hip_ab.so")
 from pyglm_amd.engine import GibbsEngine            # noqa: E402
 from pyglm_amd._lib import call, ptr                # noqa: E402
 from pyglm_amd.utils.basis import cosine_basis      # noqa: E402
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+only = sys.argv[3] if len(sys.argv) > 3 else None
 N, B, T, nl = 1024, 5, 100000, 8
 rng = np.random.default_rng(0)
 Y = (rng.random((T, N)) < 0.08).astype(float)
@@ -35,6 +41,8 @@ with torch.cuda.device(eng.dev):
               ("gram", lambda: call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), T, D, nl, k, None)),
               ("crt", lambda: call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), ptr(J), ldj, ldj * ldj, T, D, nl, k, 0, None))]
     for name, fn in stages:
+        if only and name not in ("stats", "planes", only):
+            continue
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
