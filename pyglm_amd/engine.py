@@ -343,18 +343,21 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ integer-MFMA Gram: when, and its scratch
     I8_GROUPS = (64, 32, 16, 8, 4, 2, 1)     # neurons converted and multiplied per launch (their planes are `planes` T D bytes each)
     I8_MIN_D, I8_MIN_T = 1024, 2048
-    I8_SMALL_D, I8_SMALL_T = 640, 16384      # between 640 and 1024 columns: only where the 320-tile padding leaves a gain (_i8_pays)
+    I8_SMALL_T = 16384                       # below I8_MIN_D columns: only for long data sets, and only where a cost model says so (_i8_pays)
 
     def _i8_pays(self, T, planes=13):
-        """gram='auto' below I8_MIN_D: the integer path only if a cost model says it wins by 10 %.  Per neuron and time bin, from the rates
-        measured on MI355X: fp64 kernel 2.9e-14 s per multiply-add slot of its lower 128-tiles; integer products
-        1.12e-15 s per slot and plane of the lower 320-tiles at these small item counts, plane conversion 1.9e-13 s per byte.  D = 640
-        (two tiles exactly: measured 40 against 46 ms at BASELINE configs[1]) and D = 960 pass; D = 650 (padded to 960 rows) does not."""
-        if self.D < self.I8_SMALL_D or T < self.I8_SMALL_T:
+        """gram='auto' below I8_MIN_D columns: the integer path only if a cost model says it wins by 10 %.  Per neuron and time bin, from rates
+        measured on MI355X at T = 50 000 (profiles/r04_small_D_crossover.md): the fp64 kernel takes 2.9e-14 s per multiply-add slot of its
+        lower 128-tiles; an item of the integer product (one 320-tile of one plane) 1.9e-8 s on its CU, a launch _i8_rounds item-times for
+        its group of neurons; the plane conversion 1.95e-13 s per byte.  Measured, ms per sweep int8 / fp64: D = 320 12.8 / 17.7, D = 500
+        (padded to 640) 33.6 / 33.7, D = 640 41.5 / 56, D = 650 (padded to 960) 64.3 / 79.6, D = 900 95.2 / 165.6."""
+        if T < self.I8_SMALL_T:
             return False
         nt, nq = -(-self.D // 128), -(-self.D // 320)
         t64 = nt * (nt + 1) // 2 * 128 * 128 * 2.9e-14
-        t8 = planes * (nq * (nq + 1) // 2 * 320 * 320 * 1.12e-15 + nq * 320 * 1.9e-13)
+        gmax = min(self.I8_GROUPS[0], self.nb or self.nloc)
+        G = max(g for g in self.I8_GROUPS if g <= max(1, gmax))
+        t8 = self._i8_rounds(G, nq * (nq + 1) // 2, planes) / G * 1.9e-8 + planes * nq * 320 * 1.95e-13
         return t8 < 0.9 * t64
 
     @staticmethod
@@ -384,7 +387,7 @@ class GibbsEngine(object):
         fall back to the fp64 kernel (with a warning)."""
         if self.obs == 2 or self.design_only or self.likelihood_only or self.gram == "fp64":
             return None
-        if self.gram != "int8" and (T < self.I8_MIN_T or (self.D < self.I8_MIN_D and not self._i8_pays(T))):
+        if self.gram != "int8" and (T < self.I8_MIN_T or (self.D < self.I8_MIN_D and not self._i8_pays(T, self.planes or 13))):
             return None
         lib = _lib.load()
         planes = self.planes or lib.pgl_i8_min_planes(T)

@@ -119,13 +119,15 @@ class _IndependentGaussianMixin(_NetworkModel):
         if is_diagonal_weight_special:
             nu_self = max(nu_0, B + 2.)
             if REFERENCE_QUIRKS:
-                # networks.py:94 passes nu_0 raw.  With nu_0 < B the reference cannot even be constructed (the inverse-Wishart draw of the
-                # third-party Gaussian needs nu >= B), so that case keeps the floor of :89
+                # networks.py:94 passes nu_0 raw.  An inverse-Wishart with nu < B has no density, so for nu_0 < B the floor of :89 is applied here
+                # too.  What the reference does in that case is UNVERIFIED: it hands nu_0 to pybasicbayes' Gaussian, whose source is not under
+                # /root/reference (it may raise at construction, at the first draw, or go on with an improper prior)
                 if nu_0 >= B:
                     nu_self = nu_0
                 else:
-                    warnings.warn("self-connection prior: nu_0 = %g < B = %d; the reference fails to construct this network (networks.py:94), "
-                                  "nu_0 is floored at B + 2 as at networks.py:89" % (nu_0, B), stacklevel=3)
+                    warnings.warn("self-connection prior: nu_0 = %g < B = %d is no proper inverse-Wishart; nu_0 is floored at B + 2 as at networks.py:89 "
+                                  "(the reference passes it raw to pybasicbayes at networks.py:94: behaviour unverified, package absent)" % (nu_0, B),
+                                  stacklevel=3)
             self._self_gaussian = _NIW(mu_0, sigma_0, kappa_0, nu_self)
 
     def _rows(self, off, diag, n0, n1):

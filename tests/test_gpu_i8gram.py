@@ -503,17 +503,21 @@ def test_batch_norms_give_the_scales_of_the_column_statistics(N, B, T, batch):
 
 
 def test_auto_takes_the_integer_gram_where_it_pays():
-    """gram='auto' (the default): int8 planes for large D and long T, the fp64 kernel for small shapes and for the Gaussian model"""
+    """gram='auto' (the default): int8 planes for large D and long T, the fp64 kernel for short data sets and for the Gaussian model; below
+    1024 columns a cost model from measured rates decides (GibbsEngine._i8_pays: the 320-tile padding, the item count of a launch)"""
     from pyglm_amd.engine import GibbsEngine
     rng = np.random.default_rng(0)
-    for N, B, T, obs, want in [(210, 5, 2100, "bernoulli", True), (210, 5, 1500, "bernoulli", False), (60, 3, 4000, "bernoulli", False),
-                               (210, 5, 2100, "gaussian", False),
-                               # between 640 and 1024 columns: where the 320-tile padding leaves a gain (GibbsEngine._i8_pays)
-                               (128, 5, 17000, "bernoulli", True), (130, 5, 17000, "bernoulli", False), (128, 5, 9000, "bernoulli", False)]:
-        eng = GibbsEngine(N, B, n1=4, obs=obs, batch=4)
+    for N, B, T, obs, nloc, want in [(210, 5, 2100, "bernoulli", 4, True), (210, 5, 1500, "bernoulli", 4, False), (60, 3, 4000, "bernoulli", 4, False),
+                                     (210, 5, 2100, "gaussian", 4, False),
+                                     # below 1024 columns, whole models: D = 640 and 650 (padded to 960) and 320 pay, D = 500 (padded to 640) is a tie
+                                     # and stays on the fp64 kernel, a short data set does too; two neurons of D = 640 do not fill a launch
+                                     (128, 5, 17000, "bernoulli", None, True), (130, 5, 17000, "bernoulli", None, True), (64, 5, 17000, "bernoulli", None, True),
+                                     (100, 5, 17000, "bernoulli", None, False), (128, 5, 9000, "bernoulli", None, False), (128, 5, 17000, "bernoulli", 2, False)]:
+        eng = GibbsEngine(N, B, n1=nloc, obs=obs, batch=nloc)
         ds = eng.add_data((rng.random((T, N)) < 0.1).astype(float), X=rng.random((T, N, B)) * 0.1)
-        assert eng.gram == "auto" and ds.int8 == want, (N, B, T, obs)
+        assert eng.gram == "auto" and ds.int8 == want, (N, B, T, obs, nloc)
         assert (eng._i8_scratch is not None) == want
+        del eng
 
 
 def test_non_finite_weights_give_nan_not_garbage():
