@@ -21,7 +21,7 @@ from pyglm_amd.utils.basis import cosine_basis      # noqa: E402
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 only = sys.argv[3] if len(sys.argv) > 3 else None
-N, B, T, nl = 1024, 5, 100000, 8
+N, B, T, nl = (int(os.environ.get(k, d)) for k, d in (('PN', 1024), ('PB', 5), ('PT', 100000), ('PNL', 8)))      # PN=128 PT=50000 PNL=64: BASELINE configs[1]
 rng = np.random.default_rng(0)
 Y = (rng.random((T, N)) < 0.08).astype(float)
 eng = GibbsEngine(N, B, 0, nl, batch=nl, gram="int8", planes=k)
@@ -34,8 +34,11 @@ with torch.cuda.device(eng.dev):
     om = ctypes.c_void_p(ds.OK.data_ptr())
     ldo = 2 * eng.ldn
     J = eng.Jslots[0]
-    stages = [("stats", lambda: (call("pgl_i8_colstats", ptr(ds.X), Dp, om, ldo, T, D, nl, ptr(stat[0]), ptr(stat[1]), None),
-                                 call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), nl * D, T, k, ptr(stat[2]), None))),
+    def stats():
+        for c0 in range(0, nl, 8):          # (the statistics pass takes at most 8 weight columns)
+            call("pgl_i8_colstats", ptr(ds.X), Dp, ctypes.c_void_p(om.value + 8 * c0), ldo, T, D, min(8, nl - c0), ptr(stat[0][c0:]), ptr(stat[1][c0:]), None)
+        call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), nl * D, T, k, ptr(stat[2]), None)
+    stages = [("stats", stats),
               ("planes X", lambda: call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
               ("planes", lambda: call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
               ("gram", lambda: call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), T, D, nl, k, None)),
