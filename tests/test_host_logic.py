@@ -468,20 +468,22 @@ def test_shard_override_sweeps_its_rows_only():
     assert np.isfinite(part.log_likelihood())
 
 
-def test_integer_gram_gate_between_640_and_1024_columns():
-    """gram='auto' below 1024 columns takes the integer path only where the 320-tile padding leaves a modelled gain of 10 %
-    (GibbsEngine._i8_pays; pure arithmetic, no GPU): two or three exact tiles yes, a column more than a multiple of 320 no"""
+def test_integer_gram_planning_arithmetic():
+    """host arithmetic of the integer Gram's plan (no GPU): item-times of a product launch per group size, and the cost model that decides
+    gram='auto' below 1024 columns from the rates measured in profiles/r04_small_D_crossover.md"""
+    import types
     from pyglm_amd.engine import GibbsEngine
+    r = GibbsEngine._i8_rounds
+    assert r(8, 136, 13) == 55.25            # BASELINE configs[2]: one neuron per XCD, 12 x 136 whole items + 4 x 136 quarter items on 32 CUs
+    assert r(8, 3, 13) == 2.0 and r(16, 3, 13) == 3.0 and r(32, 3, 13) == 5.0 and r(64, 3, 13) == 9.75     # configs[1]: per neuron 0.25 -> 0.152
+    assert r(5, 3, 13) == 1.0 and r(1, 5356, 13) == 272.0                                                   # flat lists (ragged groups; configs[4])
 
-    class Shape(object):
-        I8_SMALL_D, I8_SMALL_T = GibbsEngine.I8_SMALL_D, GibbsEngine.I8_SMALL_T
-
-    def pays(D, T):
-        s = Shape()
-        s.D = D
-        return GibbsEngine._i8_pays(s, T)
-
-    assert pays(640, 50000) and pays(960, 50000) and pays(640, 16384)
-    assert not pays(650, 50000) and not pays(700, 50000) and not pays(1000, 50000)       # padded to 960 / 1280 rows
-    assert not pays(639, 50000) and not pays(320, 50000) and not pays(180, 10 ** 6)      # below the floor
-    assert not pays(640, 16383)                                                           # short data sets keep the fp64 kernel
+    def pays(N, B, T, nloc=None):
+        eng = types.SimpleNamespace(D=N * B, nb=None, nloc=nloc or N, I8_SMALL_T=GibbsEngine.I8_SMALL_T, I8_GROUPS=GibbsEngine.I8_GROUPS,
+                                    _i8_rounds=GibbsEngine._i8_rounds)
+        return GibbsEngine._i8_pays(eng, T)
+    assert pays(128, 5, 50000) and pays(130, 5, 50000) and pays(64, 5, 50000) and pays(180, 5, 50000)
+    assert not pays(100, 5, 50000)           # D = 500 pads to 640: a tie with the fp64 kernel (33.6 / 33.7 ms per sweep measured)
+    assert pays(128, 5, 16384) and not pays(128, 5, 16383) and not pays(128, 5, 9000)            # short data sets keep the fp64 kernel
+    assert not pays(128, 5, 50000, nloc=2)   # two neurons do not fill a launch
+    assert not pays(32, 5, 50000)            # D = 160: one padded tile against three small fp64 tiles
