@@ -112,11 +112,12 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
  *                   over X, deterministic (fixed summation order)
  *   pgl_i8_scales   scale[k] from (amax[k], sumsq[k]) for ncols = G * D columns (1 for an empty column, NaN for a non-finite one)
  *   pgl_i8_planes   residue planes [G][nplanes] of Dq * Kp signed bytes each (Dq = pgl_i8_padded_rows(D): D rounded up to the product
- *                   kernel's tile edge, 320 -- or 256 with PGL_I8_TILE=256 in the environment; Kp = T rounded up to 64, at least 256), BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024
+ *                   kernel's tile edge, 320; Kp = T rounded up to 64, at least 256), BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024
  *                   + (r % 16) 64; of X (Om = NULL, G = 1) or of omega_g X for the G columns of Om; scale [G][D]; buffer sizes from
  *                   pgl_i8_plane_bytes (per neuron, at the full 15 planes)
  *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower-triangular tiles, [G][nplanes][Dq][Dq] signed bytes
- *                   (buffer: G * pgl_i8_residue_bytes(D))
+ *                   (buffer: G * pgl_i8_residue_bytes(D)); any G >= 1 -- multiples of 8 fill the per-XCD work lists (8 where a plane has many
+ *                   tiles, up to PGL_I8_MAX_GROUP where it has few: the launch should be several rounds of 256 items)
  *   pgl_i8_crt      J[g] (+)= X' diag(omega_g) X, lower triangle, from the residues (scale_x [D], scale_wx [G][D])
  * The same nplanes must be used for the scales, both plane sets, the product and the reconstruction. */
 int pgl_i8_max_planes(void);                     /* 15 */
@@ -266,7 +267,7 @@ typedef struct {
                                     * holds i8_group slices of pgl_i8_plane_bytes(D, i8_slice) */
     void* i8_PAs;                  /* planes of one slice of X, pgl_i8_plane_bytes(D, i8_slice or T): used for data sets with int8 = 1 and PA = NULL
                                     * (their X planes are converted per slice -- per group where there is one slice -- instead of kept) */
-    void* i8_Rx;                   /* optional: 3 * i8_group * Dq^2 bytes.  With it (and full groups of 8) the product kernel cuts the items of the LAST
+    void* i8_Rx;                   /* optional: 3 * i8_group * Dq^2 bytes.  With it (and groups that are multiples of 8) the product kernel cuts the items of the LAST
                                     * residue plane into four K quarters, which evens out its final rounds (13 x 136 items per XCD of 32 CUs at
                                     * BASELINE configs[2]: 55.25 rounds -> 51 + 17/4); the quarters' residues are added by the CRT.  NULL: no split.
                                     * Exact integer arithmetic either way: the same J to the last bit */
