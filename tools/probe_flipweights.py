@@ -5,6 +5,10 @@ active, prior rho = `rho` -- so that runs are comparable.   python tools/probe_f
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+import pyglm_amd._lib as _l
+if os.environ.get("PGL_PROBE_LIB") == "ab":         # the -DPGL_AB build (make -C pyglm_amd/csrc ab): tuning knobs from the environment
+    _l.LIB_PATH = _l.LIB_PATH.replace("libpyglm_hip.so", "libpyglm_hip_ab.so")
 from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
 from pyglm_amd.utils.basis import cosine_basis
 dens = float(sys.argv[1]) if len(sys.argv) > 1 else 0.6
