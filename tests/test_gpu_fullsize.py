@@ -362,3 +362,49 @@ def test_cfg3_two_neurons_against_the_oracle_at_full_size():
 def test_cfg4_two_neurons_against_the_oracle_at_full_size():
     """BASELINE.json configs[3] (NegativeBinomialGLM N = 512, B = 5, T = 100 000, xi = 2, dense prior: rho = 1 -- no flips, a 2561-dim draw)"""
     _oracle_at_full_size("negbin", 512, 5, 100000, rho=1.0, S_w=1.0, xi=2.0)
+
+
+def test_cfg3_whole_model_in_batches_equals_the_oracle_checked_shards():
+    """The whole model of the metric's configuration -- 1024 neurons as 4 batches of 256, groups of 8 per product launch: what bench.py times --
+    tied to the shard path the oracle checks above: one sweep of the full engine, then the same sweep on two 2-neuron shards (one inside the
+    last batch, one straddling the first batch boundary), which must reproduce the full run's rows: every random input is keyed by the global
+    neuron and the integer Gram is exact, so the decisions and the log-likelihoods agree bit for bit; the border sums X'omega are added up in
+    time slices whose number follows the shard's size (pgl_sweep.hip), which moves the log-odds in the ninth digit and the weights in the tenth."""
+    import gc
+    import torch
+    from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
+    gc.collect()
+    torch.cuda.empty_cache()
+    N, B, T = 1024, 5, 100000
+    D = N * B
+    basis, Y, rng = _problem(N, B, T)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.05 * a[:, :, None]
+    b = np.full(N, -2.0)
+    hyp = prior_terms(np.tile(np.eye(B) * 10.0, (N, N, 1, 1)), np.zeros((N, N, B)), np.ones(N), np.full(N, -2.0))
+    rho = np.full((N, N), 0.4)
+    perm, u, z = make_draws(31, 2, range(N), N, D)
+    eng = GibbsEngine(N, B)
+    ds = eng.add_data(Y, basis=basis)
+    assert ds.int8 and eng.nb == 256 and eng._i8_scratch[2] == 8
+    eng.keep_logodds = True
+    a1, W1, b1, ll1 = eng.sweep(a, W, b, rho, *hyp, perm, u, z, seed=31, sweep=2)
+    lo1 = eng.logodds.cpu().numpy()
+    assert np.all(W1[~a1] == 0) and not np.array_equal(a1, a)
+    del eng, ds
+    gc.collect()
+    torch.cuda.empty_cache()
+    for n0 in (1000, 255):
+        sl = slice(n0, n0 + 2)
+        sh = GibbsEngine(N, B, n0, n0 + 2, batch=2)
+        sh.add_data(Y, basis=basis)
+        sh.keep_logodds = True
+        a2, W2, b2, ll2 = sh.sweep(a[sl], W[sl], b[sl], rho[sl], *[h[sl] for h in hyp], perm[sl], u[sl], z[sl], seed=31, sweep=2)
+        np.testing.assert_array_equal(a2, a1[sl])
+        np.testing.assert_array_equal(ll2, ll1[sl])
+        np.testing.assert_allclose(sh.logodds.cpu().numpy(), lo1[sl], rtol=1e-8, atol=1e-7)
+        np.testing.assert_allclose(W2, W1[sl], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(b2, b1[sl], rtol=1e-7, atol=1e-9)
+        del sh
+        gc.collect()
+        torch.cuda.empty_cache()
