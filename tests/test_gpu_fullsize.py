@@ -330,7 +330,9 @@ def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21):
         Jg, hg = eng.posterior(i)
         nb_ = torch.sqrt(((ds.OK[:T, i] ** 2)[:, None] * Xd * Xd).sum(0)).cpu().numpy()
         err = np.abs(Jg[:D, :D] - Jq[:D, :D]) / np.maximum(np.outer(na, nb_), 1e-300)
-        assert err.max() < 3e-14 and np.sqrt(np.mean(err ** 2)) < 5e-15, (err.max(), np.sqrt(np.mean(err ** 2)))   # (the oracle's own dgemm included)
+        print("%s neuron %d: |J_gpu - J_oracle| / (|x_i| |omega x_j|): max %.2e, rms %.2e" % (obs, i, err.max(), np.sqrt(np.mean(err ** 2))))
+        # measured 2.7e-15 .. 3.6e-15 at the worst entry and 5.3e-16 .. 5.8e-16 rms (the oracle's own dgemm included)
+        assert err.max() < 8e-15 and np.sqrt(np.mean(err ** 2)) < 1.5e-15, (err.max(), np.sqrt(np.mean(err ** 2)))
         np.testing.assert_allclose(Jg[D, :], Jq[D, :], rtol=1e-12, atol=0)         # bias row: X' omega, sum omega (+ prior)
         np.testing.assert_allclose(hg, hq, rtol=1e-11, atol=1e-9 * np.abs(hq).max())
         del Jl, Jg, err
