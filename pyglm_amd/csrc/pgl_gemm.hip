@@ -22,6 +22,7 @@
 //     one XCD share the same X panels through that XCD's L2; the Gram is launched persistently (one workgroup per CU
 //     pulling XCD-local items) because the dispatcher's round-robin drifts over long launches.
 #include "pgl_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -259,6 +260,69 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            if constexpr (CINIT && NLD <= 8) {
+                // The read-modify-write products (rank-k updates of the tableau and the Cholesky).  PMC: their MFMA pipe is busy 0.81 of the time --
+                // the two waves of a SIMD take the pipe turn by turn and so reach their k-step boundaries together, where each reads its eight
+                // fragments and only then issues (profiles/r04_update_kernel_pmc.md).  Here the fragments of k-step kk + 1 are read in the MFMA
+                // shadows of k-step kk into a second register set.  That only fits because the ACCUMULATORS LIVE IN AGPRs: the MFMAs are issued as
+                // inline assembly with a register-class constraint (left to itself hipcc keeps the 128 accumulator registers in VGPRs and, with a
+                // second fragment set, spills accumulator tiles inside the K loop).  93 VGPRs + 128 AGPRs of the 256 a wave may have with two
+                // workgroups per CU.  Same MFMAs on the same operands in the same order: same bits.  Rank 512: 63.6 -> 65.2 TFLOP/s.
+                // (Also moving the barrier between k-steps 2 and 3, so that not even a tile's first fragments are read in the open, keeps the
+                // staged global loads alive across it: 140+ VGPRs against the 128 left beside the accumulators -- it spills and runs at 55.)
+                double fa0[4], fb0[4], fa1[4], fb1[4];
+                auto rd_first = [&](int buf) {             // k-step 0 of the tile in `buf` (just published by the barrier): the one read in the open
+                    const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
+                    const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa0[i] = As[frow * C::SA + i * 16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb0[j] = Bs[frow * C::SB + j * 16];
+                };
+                auto kstep_a = [&](int buf, auto kk_c, auto hook) {       // k-step KK on register set KK & 1; KK < 3: prefetches k-step KK + 1
+                    constexpr int KK = decltype(kk_c)::value;
+                    double (&ca)[4] = (KK & 1) ? fa1 : fa0;
+                    double (&cb)[4] = (KK & 1) ? fb1 : fb0;
+                    double (&na)[4] = (KK & 1) ? fa0 : fa1;
+                    double (&nb)[4] = (KK & 1) ? fb0 : fb1;
+                    const double* As = smem + buf * C::STAGE + wm * 64 + fcol;
+                    const double* Bs = smem + buf * C::STAGE + C::A_ELEMS + wn * 64 + fcol;
+                    const int krn = (KK + 1) * 4 + frow;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[m >> 2][m & 3]) : "v"(ca[m >> 2]), "v"(cb[m & 3]));
+                        if constexpr (KK < 3) {
+                            if (m < 4) na[m] = As[krn * C::SA + m * 16];
+                            else if (m < 8) nb[m - 4] = Bs[krn * C::SB + (m - 4) * 16];
+                        }
+                        hook(m);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+                using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+                auto nohook = [](int) {};
+                rd_first(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the accumulators were just written (C tile): wait states before the first MFMA reads them
+                for (int kt = 0; kt + 1 < nkt; ++kt) {
+                    const int buf = kt & 1;
+                    kstep_a(buf, K0{}, [&](int m) { if (m >= 8 && m - 8 < NLD) gload_piece(m - 8); });
+                    ka_ += stepA; kb_ += stepB;
+                    kstep_a(buf, K1{}, nohook);
+                    kstep_a(buf, K2{}, nohook);
+                    kstep_a(buf, K3{}, [&](int m) { if (m >= 16 - NLD) lstore_piece(buf ^ 1, m - (16 - NLD)); });
+                    __syncthreads();
+                    rd_first(buf ^ 1);
+                }
+                {
+                    const int buf = (nkt - 1) & 1;
+                    kstep_a(buf, K0{}, nohook);
+                    kstep_a(buf, K1{}, nohook);
+                    kstep_a(buf, K2{}, nohook);
+                    kstep_a(buf, K3{}, nohook);
+                }
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results readable
+            } else {
             for (int kt = 0; kt + 1 < nkt; ++kt) {
                 const int buf = kt & 1;
                 kstep(buf, 0, [&](int m) { if (m < NLD) gload_piece(m); });
@@ -272,6 +336,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
                 const int buf = (nkt - 1) & 1;
 #pragma unroll
                 for (int kk = 0; kk < BK / 4; ++kk) compute(buf, kk);
+            }
             }
         } else {
             for (int kt = 0; kt < nkt; ++kt) {
