@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 8
+#define PGL_ABI_VERSION 9
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -100,7 +100,9 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
 
 /* ---- the same weighted Gram on the INTEGER matrix cores -------------------------------------------
  * X'OX of pyglm/regression.py:251-252 computed exactly on operands rounded, column by column, to integers
- *     A[t][i] = rint(x_ti sA_i),   B_g[t][j] = rint((omega_gt x_tj) sB_gj),      sA, sB powers of two,
+ *     A[t][i] = round(x_ti sA_i),  B_g[t][j] = rint((omega_gt x_tj) sB_gj),      sA, sB powers of two,
+ * (the columns of X, whose values repeat from bin to bin, are rounded with a dither u(t, i) in [0, 1) -- a fixed hash of the GLOBAL time bin and
+ * the column: floor(v) + [frac(v) + u >= 1], unbiased and independent across bins, exact for integer v; omega_gt x_tj to the nearest integer)
  * one int8 GEMM per modulus for the first `nplanes` of 15 pairwise coprime moduli <= 256 (256, 255, 253, 251, 247, 241, 239, 233, 229,
  * 227, 223, 217, 211, 199, 197), int32 accumulation (re-reduced every 128 000 bins), exact Chinese-remainder reconstruction,
  * J_ij = (S_ij / sA_i) / sB_gj.  The scales are set from each column's Euclidean norm and largest element so that the integer columns have
@@ -114,7 +116,8 @@ int pgl_assemble_posterior(double* J, long ldj, long strideJ, const double* bord
  *   pgl_i8_planes   residue planes [G][nplanes] of Dq * Kp signed bytes each (Dq = pgl_i8_padded_rows(D): D rounded up to the product
  *                   kernel's tile edge, 320; Kp = T rounded up to 64, at least 256), BLOCKED as [Dq / 16][Kp / 64][16][64]: the 64 time bins of K tile k of row r are at ((r / 16) (Kp / 64) + k) 1024
  *                   + (r % 16) 64; of X (Om = NULL, G = 1) or of omega_g X for the G columns of Om; scale [G][D]; buffer sizes from
- *                   pgl_i8_plane_bytes (per neuron, at the full 15 planes)
+ *                   pgl_i8_plane_bytes (per neuron, at the full 15 planes); t0 = index in its data set of the first bin given (0 unless X is
+ *                   converted in time slices): it keys the dither of the X planes, so that slices give the integers of the whole
  *   pgl_i8_gram     residues[g][q] = (planes_x[q] planes_wx[g][q]') mod p_q, lower-triangular tiles, [G][nplanes][Dq][Dq] signed bytes
  *                   (buffer: G * pgl_i8_residue_bytes(D)); any G >= 1 -- multiples of 8 fill the per-XCD work lists (8 where a plane has many
  *                   tiles, up to PGL_I8_MAX_GROUP where it has few: the launch should be several rounds of 256 items)
@@ -130,11 +133,11 @@ size_t pgl_i8_residue_bytes(int D);
 int pgl_i8_colstats(const double* X, long ldx, const double* Om, long ldo, int T, int D, int G, double* amax, double* sumsq, void* hip_stream);
 int pgl_i8_scales(const double* amax, const double* sumsq, long ncols, int T, int nplanes, double* scale, void* hip_stream);
 int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
-                  void* hip_stream);
+                  long t0, void* hip_stream);
 /* the same planes, byte for byte, read from the TRANSPOSED copy Xt [D][ldt] (what pgl_design_matrix / pgl_transpose also produce): its rows
  * are contiguous in time, which is the order the planes are written in -- 5-8 % faster at cfg3; what pgl_sweep uses */
 int pgl_i8_planes_t(const double* Xt, long ldt, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
-                    void* hip_stream);
+                    long t0, void* hip_stream);
 int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, int nplanes, void* hip_stream);
 /* One time slice [t0, t0 + T_slice) of the same product, for data sets whose planes do not fit in memory at once (BASELINE configs[4]:
  * 86 GB of planes per neuron): planes_wx holds the slice only (pgl_i8_planes_t on the slice's rows); planes_x either the whole data set

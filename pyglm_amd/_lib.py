@@ -70,8 +70,8 @@ SIGNATURES = {
     "pgl_i8_norm_limit": [c_i, c_i],
     "pgl_i8_colstats": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
     "pgl_i8_scales": [c_p, c_p, c_l, c_i, c_i, c_p, c_p],
-    "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "pgl_i8_planes_t": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "pgl_i8_planes": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_p],
+    "pgl_i8_planes_t": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_p],
     "pgl_i8_gram": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_gram_slice": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pgl_i8_crt": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -94,7 +94,7 @@ SIGNATURES = {
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

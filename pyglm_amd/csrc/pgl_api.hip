@@ -173,18 +173,18 @@ int pgl_i8_scales(const double* amax, const double* sumsq, long ncols, int T, in
     return pgl_k_i8_scales(amax, sumsq, ncols, T, nplanes, scale, ST(st));
 }
 int pgl_i8_planes(const double* X, long ldx, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
-                  void* st) {
-    PGL_CHECK_ARG(X && scale && planes && T > 0 && D > 0 && G > 0 && ldx >= D && (Om == nullptr || ldo >= G));
+                  long t0, void* st) {
+    PGL_CHECK_ARG(X && scale && planes && T > 0 && D > 0 && G > 0 && ldx >= D && (Om == nullptr || ldo >= G) && t0 >= 0);
     PGL_CHECK_ARG(Om != nullptr || G == 1);
     PGL_CHECK_PLANES(nplanes, T);
-    return pgl_k_i8_planes(X, ldx, 0, Om, ldo, scale, static_cast<int8_t*>(planes), T, D, G, nplanes, ST(st));
+    return pgl_k_i8_planes(X, ldx, 0, Om, ldo, scale, static_cast<int8_t*>(planes), T, D, G, nplanes, t0, ST(st));
 }
 int pgl_i8_planes_t(const double* Xt, long ldt, const double* Om, long ldo, const double* scale, void* planes, int T, int D, int G, int nplanes,
-                    void* st) {
-    PGL_CHECK_ARG(Xt && scale && planes && T > 0 && D > 0 && G > 0 && ldt >= T && (Om == nullptr || ldo >= G));
+                    long t0, void* st) {
+    PGL_CHECK_ARG(Xt && scale && planes && T > 0 && D > 0 && G > 0 && ldt >= T && (Om == nullptr || ldo >= G) && t0 >= 0);
     PGL_CHECK_ARG(Om != nullptr || G == 1);
     PGL_CHECK_PLANES(nplanes, T);
-    return pgl_k_i8_planes(Xt, ldt, 1, Om, ldo, scale, static_cast<int8_t*>(planes), T, D, G, nplanes, ST(st));
+    return pgl_k_i8_planes(Xt, ldt, 1, Om, ldo, scale, static_cast<int8_t*>(planes), T, D, G, nplanes, t0, ST(st));
 }
 int pgl_i8_gram(const void* planes_x, const void* planes_wx, void* residues, int T, int D, int G, int nplanes, void* st) {
     PGL_CHECK_ARG(planes_x && planes_wx && residues && T > 0 && D > 0 && G > 0);

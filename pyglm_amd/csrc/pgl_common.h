@@ -122,7 +122,7 @@ int pgl_k_i8_colmax(const double*, long, int, int, double*, hipStream_t);
 int pgl_k_i8_scales_bound(const double*, long, const double*, const double*, int, int, int, int, double*, hipStream_t);
 size_t pgl_k_i8_stats_scratch_doubles(int, int);
 int pgl_k_i8_colstats_scales(const double*, long, const double*, long, int, int, int, int, double*, double*, hipStream_t);
-int pgl_k_i8_planes(const double*, long, int transposed, const double*, long, const double*, int8_t*, int, int, int, int, hipStream_t);
+int pgl_k_i8_planes(const double*, long, int transposed, const double*, long, const double*, int8_t*, int, int, int, int, long t_base, hipStream_t);
 int pgl_k_i8_gram(const int8_t*, long, int, const int8_t*, int8_t*, int8_t*, int, int, int, int, int, hipStream_t);
 long pgl_k_i8_kp(int);
 int pgl_k_i8_crt(const int8_t*, const int8_t*, const double*, const double*, double*, long, long, int, int, int, int, hipStream_t);

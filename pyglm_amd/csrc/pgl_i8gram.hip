@@ -1,6 +1,6 @@
 // The omega-weighted Gram  J_n = X' diag(omega_n) X  by exact integer arithmetic on the int8 MFMA (the engine's choice at large shapes,
 // the fp64 kernel of pgl_gemm.hip otherwise).  The fp64 operands are scaled COLUMN BY COLUMN to integers,
-//     A[t][i] = rint(x_ti sA_i),      B_n[t][j] = rint((omega_nt x_tj) sB_nj),
+//     A[t][i] = round(x_ti sA_i),     B_n[t][j] = rint((omega_nt x_tj) sB_nj),
 // with power-of-two scales chosen from each column's Euclidean norm and largest element (i8_colstats_kernel, i8_scales_kernel):
 //     |A_i|_2, |B_nj|_2 in (limit(K, T) / 2, limit(K, T)]   unless the largest element would reach 2^50 (then that bound decides),
 // so that by Cauchy-Schwarz every entry of the integer Gram S = A'B_n obeys |S_ij| <= |A_i||B_nj| < prod(p)/2 for the K <= 15 pairwise
@@ -10,8 +10,13 @@
 // independent roundings the error of J_ij has standard deviation sqrt((|A_i|^-2 + |B_nj|^-2) / 12) |a_i||b_nj|, i.e. 2.1e-16 .. 4.2e-16
 // |a_i||b_j| at K = 13 (a column whose norm is one outlier element is held at 2^49..2^50 by the element bound at every K) -- for ANY
 // dynamic range: the precision is pinned to the column norms, not to the column maxima.  Roundings of REPEATED values are not independent
-// (a design matrix of filtered spikes takes few distinct values per column): measured on the bench's data the error is ~5x that model,
-// still several times below the fp64 kernel's own (tests/test_gpu_i8gram.py).
+// (a design matrix of filtered spikes takes few distinct values per column, and every occurrence of a value rounds the same way: with
+// plain round-to-nearest the error was ~5x that model on BASELINE configs[2]'s data and 1e-14 |a_i||b_j| at the worst entry on configs[4]'s,
+// whose narrow first basis function leaves ~1000 distinct values in a column of 200 000).  The columns of X -- the operand that repeats;
+// omega_nt x_tj does not -- are therefore rounded with a DITHER: round(v) = floor(v) + [frac(v) + u(t, i) >= 1], u a hash of the time bin and
+// the column in [0, 1) (pgl_i8_dither): unbiased, independent from bin to bin, exact for integers (frac = 0 never rounds up), the same
+// integers whatever the slicing or the launch geometry.  Emulated in NumPy on configs[4]-shaped data: worst entry 1.2e-14 -> 1.2e-15, rms
+// 4.1e-15 -> 3.1e-16; configs[2]-shaped: 2.2e-15 -> 1.3e-15, 6.0e-16 -> 4.2e-16 (tests/test_gpu_i8gram.py).
 //
 //   i8_colstats_kernel max_t |v| and sum_t v^2 per column of X (once per data set) and of omega_g X (per neuron and sweep), deterministic
 //   i8_scales_kernel   the scale of every column from those statistics
@@ -204,7 +209,21 @@ struct PlaneArgs {
     const double* scale;                  // [G][D] fixed-point scale of column d of neuron g (i8_scales_kernel)
     int8_t* P;                            // [G][np] planes of Dq * Kp bytes, blocked [Dq / 16][Kp / 64][16][64]
     int T, D, Dq; long Kp; int np;
+    unsigned t_base;                      // global index of time bin 0 of this call (a time slice of a data set): keys the dither of the X planes
 };
+
+// u(t, d) in [0, 1): the dither of element (time bin t, column d) of X -- two rounds of a 32-bit integer mixer ("lowbias32").  Specified here and
+// restated in NumPy by tests/test_gpu_i8gram.py; keyed by the GLOBAL time bin, so a data set converted in slices gets the same integers.
+__device__ __forceinline__ unsigned pgl_mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ double pgl_i8_dither(unsigned t, unsigned d) { return (double)pgl_mix32(t + pgl_mix32(d + 0x9e3779b9u)) * (1.0 / 4294967296.0); }
+// round(y) with dither u: floor(y) + [frac(y) + u >= 1]  (y = x * scale is exact: the scale is a power of two)
+__device__ __forceinline__ double pgl_round_dither(double y, double u) {
+    const double fl = floor(y);
+    return fl + (((y - fl) + u >= 1.0) ? 1.0 : 0.0);
+}
 
 // A workgroup converts 256 time bins x 16 columns (one row block, four K tiles) of X, staged ONCE in LDS, for all G neurons of the group.
 // Wave w owns K tile w: lane l -> column l / 4, 16 consecutive time bins (one 16-byte chunk of the 64-byte row), so a wave stores one
@@ -252,7 +271,8 @@ __global__ __launch_bounds__(PT_T) void i8_planes_kernel(PlaneArgs a, int G) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const double x = tile[r][tb + k];
-            v[k] = rint((a.Om ? x * oms[tb + k] : x) * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
+            v[k] = a.Om ? rint((x * oms[tb + k]) * scale)           // x * omega rounded to fp64 first, as X*omega[:,None] is
+                        : pgl_round_dither(x * scale, pgl_i8_dither(a.t_base + (unsigned)(t0 + tb + k), (unsigned)d));     // the planes of X: dithered
             vm[k] = v[k] + MAGIC;                                   // exact: integers below 2^53
         }
         int8_t* dst = dst0 + (long)gz * a.np * plane;
@@ -334,7 +354,8 @@ __global__ __launch_bounds__(PT_T) void i8_planes_t_kernel(PlaneArgs a, int G) {
         double v[16], vm[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            v[k] = rint((a.Om ? x[k] * oms[gz][tb + k] : x[k]) * scale);      // x * omega rounded to fp64 first, as X*omega[:,None] is
+            v[k] = a.Om ? rint((x[k] * oms[gz][tb + k]) * scale)              // x * omega rounded to fp64 first, as X*omega[:,None] is
+                        : pgl_round_dither(x[k] * scale, pgl_i8_dither(a.t_base + (unsigned)(t0 + tb + k), (unsigned)d));
             vm[k] = v[k] + MAGIC;
         }
         int8_t* dst = dst0 + (long)gz * a.np * plane;
@@ -761,13 +782,14 @@ int pgl_k_i8_padded_rows(int D) { return (D + BT - 1) / BT * BT; }     // planes
 static long pgl_i8_kp(int T) { const long k = ((long)T + 63) / 64 * 64; return k < 256 ? 256 : k; }
 
 // The integer columns' norms are kept at or below limit(K, T), the largest value with
-//     (limit (1 + 1e-9) + 0.75 sqrt(T) + 1)^2 <= prod(p_0..p_{K-1}) / 2
-// (rounding a scaled column to integers adds at most sqrt(T)/2 to its norm, the fp64 product x * scale another sqrt(T)/8 at most), so
+//     (limit (1 + 1e-9) + sqrt(T) + 1)^2 <= prod(p_0..p_{K-1}) / 2
+// (rounding a scaled column of omega X to the nearest integers adds at most sqrt(T)/2 to its norm, the dithered rounding of a column of X at
+// most sqrt(T), the fp64 products another sqrt(T)/8 at most: (L + 1.125 sqrt T)(L + 0.625 sqrt T) <= (L + sqrt T)^2), so
 // |S_ij| <= |A_i||B_j| stays inside the symmetric CRT range.  nu = floor(log2(limit)): 46 / 50 / 54 / 58 for K = 12 / 13 / 14 / 15.
 double pgl_k_i8_norm_limit(int nplanes, int T) {
     double l2 = 0.0;
     for (int q = 0; q < nplanes && q < NP; ++q) l2 += std::log2((double)MT.p[q]);
-    const double lim = (std::exp2((l2 - 1.0) * 0.5) - 0.75 * std::sqrt((double)(T < 1 ? 1 : T)) - 1.0) / (1.0 + 1e-9);
+    const double lim = (std::exp2((l2 - 1.0) * 0.5) - std::sqrt((double)(T < 1 ? 1 : T)) - 1.0) / (1.0 + 1e-9);
     return lim > 0.0 ? lim : 0.0;
 }
 int pgl_k_i8_nu(int nplanes, int T) {
@@ -859,7 +881,7 @@ int pgl_k_i8_scales(const double* amax, const double* ss, long n, int T, int npl
 
 // residue planes of X (Om == null, G = 1) or of omega_g X for the G weight columns Om[:, 0..G)
 int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om, long ldo, const double* scale, int8_t* P, int T, int D, int G,
-                    int nplanes, hipStream_t st) {
+                    int nplanes, long t_base, hipStream_t st) {
     const int Dq = pgl_k_i8_padded_rows(D);
     const long Kp = pgl_i8_kp(T);
     // 512 time bins per workgroup: 8 KiB contiguous per plane and row block.  Measured on one box, ms per group of 8 at cfg3, with the
@@ -867,7 +889,7 @@ int pgl_k_i8_planes(const double* X, long ldx, int transposed, const double* Om,
     const bool aligned = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
     for (int g0 = 0; g0 < G; g0 += CS_G) {                     // (the kernels stage at most CS_G weight columns; larger groups go in pieces)
         const int gz = G - g0 < CS_G ? G - g0 : CS_G;
-        PlaneArgs a{X, ldx, transposed, Om ? Om + g0 : nullptr, ldo, scale + (long)g0 * D, P + (long)g0 * nplanes * Dq * Kp, T, D, Dq, Kp, nplanes};
+        PlaneArgs a{X, ldx, transposed, Om ? Om + g0 : nullptr, ldo, scale + (long)g0 * D, P + (long)g0 * nplanes * Dq * Kp, T, D, Dq, Kp, nplanes, (unsigned)t_base};
         if (transposed && aligned)
             // measured on one box per variant pair, ms per group of 8 at cfg3 (the LDS-tile kernel on Xt: 11.9): 768 threads 11.3-11.4, 512 10.7-10.8
             // (137 VGPRs, one workgroup per CU; forced to 128 VGPRs with 16 spills: 11.3-11.4), 256 9.85-10.1, 128 10.3-10.6

@@ -322,8 +322,8 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     for (int t0 = 0; t0 < d.T; t0 += slice) {
                         const int ts = slice < d.T - t0 ? slice : d.T - t0;
                         m = clk.tic(ST_PLANES, (double)np * (gz + (d.PA ? 0 : 1)) * ts * D);
-                        if (!d.PA) RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, nullptr, 0, d.sA, static_cast<int8_t*>(s->i8_PAs), ts, (int)D, 1, np, st));
-                        RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, om + (long)t0 * 2 * ldn, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), ts, (int)D, gz, np, st));   // (coalesced rows of Xt)
+                        if (!d.PA) RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, nullptr, 0, d.sA, static_cast<int8_t*>(s->i8_PAs), ts, (int)D, 1, np, t0, st));
+                        RC(pgl_k_i8_planes(d.Xt + t0, d.Tp, 1, om + (long)t0 * 2 * ldn, 2 * ldn, sB, static_cast<int8_t*>(s->i8_PB), ts, (int)D, gz, np, t0, st));   // (coalesced rows of Xt)
                         clk.toc(m);
                         m = clk.tic(ST_I8, (double)gz * ts * D * (D + 1));
                         if (d.PA) RC(pgl_k_i8_gram(static_cast<const int8_t*>(d.PA), pgl_k_i8_kp(d.T), t0 / 64, static_cast<const int8_t*>(s->i8_PB),

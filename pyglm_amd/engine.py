@@ -329,7 +329,7 @@ class GibbsEngine(object):
             ds.PA = None
             if plan["resident"]:
                 ds.PA = torch.empty(lib.pgl_i8_plane_bytes(self.D, T) // lib.pgl_i8_max_planes() * ds.planes, dtype=torch.int8, device=self.dev)
-                call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, st)
+                call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, None, 0, ptr(ds.sA), ptr(ds.PA), T, self.D, 1, ds.planes, 0, st)
             self._i8_reserve(T, plan)
             torch.cuda.synchronize(self.dev)
         if self.obs == 2:
@@ -695,7 +695,7 @@ class GibbsEngine(object):
             call("pgl_i8_colstats", ptr(ds.X), Dp, ctypes.c_void_p(om.value + 8 * c0), ldo, ds.T, D, cz, ptr(stat[0][c0:]), ptr(stat[1][c0:]), st)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), gz * D, ds.T, npl, ptr(stat[2]), st)
         if not S and ds.PA is not None:
-            call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, st)
+            call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), ds.T, D, gz, npl, 0, st)
             call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, D, gz, npl, st)
         else:
             S = S or ds.T
@@ -704,8 +704,8 @@ class GibbsEngine(object):
                 xt = ctypes.c_void_p(ds.Xt.data_ptr() + 8 * t0)
                 omt = ctypes.c_void_p(om.value + 8 * t0 * ldo)
                 if ds.PA is None:
-                    call("pgl_i8_planes_t", xt, ds.Tp, None, 0, ptr(ds.sA), ptr(PAs), ts, D, 1, npl, st)
-                call("pgl_i8_planes_t", xt, ds.Tp, omt, ldo, ptr(stat[2]), ptr(PB), ts, D, gz, npl, st)
+                    call("pgl_i8_planes_t", xt, ds.Tp, None, 0, ptr(ds.sA), ptr(PAs), ts, D, 1, npl, t0, st)
+                call("pgl_i8_planes_t", xt, ds.Tp, omt, ldo, ptr(stat[2]), ptr(PB), ts, D, gz, npl, t0, st)
                 call("pgl_i8_gram_slice", ptr(ds.PA) if ds.PA is not None else ptr(PAs), ds.T if ds.PA is not None else 0, t0, ptr(PB), ptr(R), ts, ds.T,
                      D, gz, npl, int(t0 > 0), st)
         call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), Jp, ldj, ldj * ldj, ds.T, D, gz, npl, accumulate, st)

@@ -48,8 +48,8 @@ def main(k=13, G=8, reps=5, D=5120, T=100000):
     timeit("colstats omega X (G = %d)" % G, lambda: call("pgl_i8_colstats", ptr(X), Dp, ptr(Om), G, T, D, G, ptr(stat[0]), ptr(stat[1]), None),
            work=8.0 * T * D, unit="GB/s")
     call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), G * D, T, k, ptr(sB), None)
-    timeit("planes X (G = 1)", lambda: call("pgl_i8_planes", ptr(X), Dp, None, 0, ptr(sA), ptr(PA), T, D, 1, k, None), work=(8.0 + k) * T * D, unit="GB/s")
-    timeit("planes omega X (G = %d)" % G, lambda: call("pgl_i8_planes", ptr(X), Dp, ptr(Om), G, ptr(sB), ptr(PB), T, D, G, k, None),
+    timeit("planes X (G = 1)", lambda: call("pgl_i8_planes", ptr(X), Dp, None, 0, ptr(sA), ptr(PA), T, D, 1, k, 0, None), work=(8.0 + k) * T * D, unit="GB/s")
+    timeit("planes omega X (G = %d)" % G, lambda: call("pgl_i8_planes", ptr(X), Dp, ptr(Om), G, ptr(sB), ptr(PB), T, D, G, k, 0, None),
            work=(8.0 + k * G) * T * D, unit="GB/s")
     timeit("gram, converted planes", lambda: call("pgl_i8_gram", ptr(PA), ptr(PB), ptr(R), T, D, G, k, None), work=ops, unit="TOP/s")
     timeit("crt", lambda: call("pgl_i8_crt", ptr(R), ptr(sA), ptr(sB), ptr(J), ldj, ldj * ldj, T, D, G, k, 0, None))

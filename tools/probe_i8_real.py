@@ -39,8 +39,8 @@ with torch.cuda.device(eng.dev):
             call("pgl_i8_colstats", ptr(ds.X), Dp, ctypes.c_void_p(om.value + 8 * c0), ldo, T, D, min(8, nl - c0), ptr(stat[0][c0:]), ptr(stat[1][c0:]), None)
         call("pgl_i8_scales", ptr(stat[0]), ptr(stat[1]), nl * D, T, k, ptr(stat[2]), None)
     stages = [("stats", stats),
-              ("planes X", lambda: call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
-              ("planes", lambda: call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, None)),
+              ("planes X", lambda: call("pgl_i8_planes", ptr(ds.X), Dp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, 0, None)),
+              ("planes", lambda: call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, om, ldo, ptr(stat[2]), ptr(PB), T, D, nl, k, 0, None)),
               ("gram", lambda: call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), T, D, nl, k, None)),
               ("crt", lambda: call("pgl_i8_crt", ptr(R), ptr(ds.sA), ptr(stat[2]), ptr(J), ldj, ldj * ldj, T, D, nl, k, 0, None))]
     for name, fn in stages:

@@ -28,7 +28,7 @@ with torch.cuda.device(eng.dev):
         def run():
             for g0 in range(0, nl, g):
                 call("pgl_i8_planes_t", ptr(ds.Xt), ds.Tp, ctypes.c_void_p(ds.OK.data_ptr() + 8 * g0), ldo,
-                     ctypes.c_void_p(stat[2].data_ptr() + 8 * g0 * D), ctypes.c_void_p(PB.data_ptr() + g0 * k * plane), T, D, g, k, None)
+                     ctypes.c_void_p(stat[2].data_ptr() + 8 * g0 * D), ctypes.c_void_p(PB.data_ptr() + g0 * k * plane), T, D, g, k, 0, None)
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
