@@ -192,10 +192,11 @@ def test_cfg5_shape_sweep_with_flips():
             got = eng.Jbuf[i, rows, cols].cpu().numpy()                # (off-diagonal blocks below the diagonal: the block-diagonal prior adds nothing)
             den = np.outer(np.sqrt((Xr * Xr).sum(0)), np.sqrt(((om[:, None] * Xc) ** 2).sum(0)))
             err = np.abs(got - want) / np.maximum(den, 1e-300)
-            # measured 1.0e-14 at the worst entry: this configuration's first basis functions are narrow, their columns take few distinct values,
-            # and repeated values round the same way (pgl_i8gram.hip) -- the level of the fp64 MFMA kernel's own worst entries (2.4e-14)
+            # measured 1.0e-15 .. 1.4e-15 at the worst entry, 2.9e-16 .. 3.3e-16 rms.  (With X rounded to nearest it was 1.0e-14 / 3.6e-15: this
+            # configuration's first basis functions are narrow, their columns take few distinct values, and repeated values rounded the same
+            # way -- the reason the planes of X are dithered, pgl_i8gram.hip.)
             print("cfg5 block (%d, %d) neuron %d: max error %.2e, rms %.2e of |x_i||omega x_j|" % (r0, c0, i, err.max(), np.sqrt(np.mean(err ** 2))))
-            assert err.max() < 3e-14 and np.sqrt(np.mean(err ** 2)) < 1e-14, (r0, c0, i, err.max())
+            assert err.max() < 3e-15 and np.sqrt(np.mean(err ** 2)) < 7e-16, (r0, c0, i, err.max())
     for i in range(nloc):
         M = torch.tril(eng.Jbuf[i, :D + 2, :D + 2])
         m = torch.from_numpy(np.concatenate((np.repeat(a1[i], B), [True]))).cuda()
