@@ -12,8 +12,8 @@ import torch
 sys.path.insert(0, ".")
 import os                                           # noqa: E402
 import pyglm_amd._lib as _l                         # noqa: E402
-if os.environ.get("PGL_PROBE_LIB") == "ab":
-    _l.LIB_PATH = _l.LIB_PATH.replace("libpyglm_hip.so", "libpyglm_hip_ab.so")
+if os.environ.get("PGL_PROBE_LIB"):                 # "ab", or a variant built by hand next to it ("ab1": lib/libpyglm_hip_ab1.so)
+    _l.LIB_PATH = _l.LIB_PATH.replace("libpyglm_hip.so", "libpyglm_hip_%s.so" % os.environ["PGL_PROBE_LIB"])
 from pyglm_amd.engine import GibbsEngine            # noqa: E402
 from pyglm_amd._lib import call, ptr                # noqa: E402
 from pyglm_amd.utils.basis import cosine_basis      # noqa: E402
@@ -46,6 +46,8 @@ with torch.cuda.device(eng.dev):
     for name, fn in stages:
         if only and name not in ("stats", "planes", only):
             continue
+        if name == "gram" and os.environ.get("PZERO"):        # PZERO=1: the product on all-zero planes (same addresses, no switching in the multipliers)
+            ds.PA.zero_(); PB.zero_()
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
