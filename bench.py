@@ -517,6 +517,12 @@ def main():
                                "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,
                                "frac_vs_ubench": ach / UBENCH_I8_MFMA_TOPS, "ubench_tops": UBENCH_I8_MFMA_TOPS,
                                "power_limited_mfma_only_tops": 4000.0}
+            busy_path = os.path.join(ROOT, "profiles", "i8_busy_pmc.json")
+            if tr_ok and os.path.exists(busy_path):
+                try:      # effective clock / MFMA-busy / wait counters of this kernel at this geometry: committed rocprofv3 --pmc passes, NOT measured in this run
+                    out["roofline"]["issue_counters"] = dict(json.load(open(busy_path)), source="profiles/i8_busy_pmc.json (committed; not measured in this run)")
+                except Exception:
+                    pass
             gp = stage("gram.planes")
             if gp["ms"] > 0:
                 # i8_planes_kernel: reads X once per group (8 B per element) and stores `planes` bytes per element and neuron
