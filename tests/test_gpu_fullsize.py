@@ -307,7 +307,7 @@ def test_cfg4_full_size_sweep_int8_equals_fp64():
     _fullsize_sweep_checks("negbin", 512, 5, 100000, 8, rho=1.0, S_w=1.0, xi=2.0)
 
 
-def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21):
+def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21, nloc=2, gram="auto"):
     """Two neurons of a BASELINE.json configuration at its OWN size, one sweep through the default path (gram='auto': the integer Gram),
     against the oracle -- the NumPy restatement of regression.py:225-262, 282-320, 323-340 on the box's host cores -- fed the GPU's own
     omega: (i) the assembled posterior (J, h) against prior_stats + lkhd_stats, error relative to |x_i| |omega x_j|; (ii) the first `nprop`
@@ -322,15 +322,15 @@ def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21):
     basis, Y, rng = _problem(N, B, T)
     if obs == "negbin":
         Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)
-    D, nloc = N * B, 2
+    D = N * B
     a = rng.random((nloc, N)) < (1.0 if rho == 1.0 else 0.6)
     W = rng.standard_normal((nloc, N, B)) * 0.05 * a[:, :, None]
     b = np.full(nloc, -2.0)
     hyp = prior_terms(np.tile(np.eye(B) * S_w, (nloc, N, 1, 1)), np.zeros((nloc, N, B)), np.ones(nloc), np.full(nloc, -2.0))
     perm, u, z = make_draws(seed, 0, range(nloc), N, D)
-    eng = GibbsEngine(N, B, 0, nloc, batch=nloc, obs=obs, xi=xi)
+    eng = GibbsEngine(N, B, 0, nloc, batch=nloc, obs=obs, xi=xi, gram=gram)
     ds = eng.add_data(Y, basis=basis)
-    assert eng.gram == "auto" and ds.int8                      # the path the benchmark runs
+    assert eng.gram == gram and ds.int8                        # the path the benchmark runs
     eng.keep_logodds = True
     a1, W1, b1, ll1 = eng.sweep(a, W, b, np.full((nloc, N), rho), *hyp, perm, u, z, seed=seed, sweep=0)
     lo = eng.logodds.cpu().numpy()
@@ -350,7 +350,8 @@ def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21):
         Jg, hg = eng.posterior(i)
         nb_ = torch.sqrt(((ds.OK[:T, i] ** 2)[:, None] * Xd * Xd).sum(0)).cpu().numpy()
         err = np.abs(Jg[:D, :D] - Jq[:D, :D]) / np.maximum(np.outer(na, nb_), 1e-300)
-        print("%s neuron %d: |J_gpu - J_oracle| / (|x_i| |omega x_j|): max %.2e, rms %.2e" % (obs, i, err.max(), np.sqrt(np.mean(err ** 2))))
+        if nloc <= 4 or i % 16 == 0:
+            print("%s neuron %d: |J_gpu - J_oracle| / (|x_i| |omega x_j|): max %.2e, rms %.2e" % (obs, i, err.max(), np.sqrt(np.mean(err ** 2))))
         # measured 2.7e-15 .. 3.6e-15 at the worst entry and 5.3e-16 .. 5.8e-16 rms (the oracle's own dgemm included)
         assert err.max() < 8e-15 and np.sqrt(np.mean(err ** 2)) < 1.5e-15, (err.max(), np.sqrt(np.mean(err ** 2)))
         np.testing.assert_allclose(Jg[D, :], Jq[D, :], rtol=1e-12, atol=0)         # bias row: X' omega, sum omega (+ prior)
@@ -380,6 +381,14 @@ def _oracle_at_full_size(obs, N, B, T, rho, S_w, xi=1.0, nprop=32, seed=21):
 def test_cfg3_two_neurons_against_the_oracle_at_full_size():
     """BASELINE.json configs[2], the metric's own configuration (SparseBernoulliGLM N = 1024, B = 5, T = 100 000)"""
     _oracle_at_full_size("bernoulli", 1024, 5, 100000, rho=0.5, S_w=10.0)
+
+
+def test_cfg2_whole_model_every_proposal_against_the_oracle_at_full_size():
+    """BASELINE.json configs[1] (SparseBernoulliGLM N = 128, B = 5, T = 50 000), the WHOLE model through the default path (gram='auto' takes the
+    integer Gram for the 128 neurons of this configuration, 64 per product launch: what bench.py --config cfg2 times): the posterior system of all
+    128 neurons, ALL 128 flip proposals of each (16 384 decisions, bit-equal; log-odds to 1e-8) and every weight draw against the oracle -- whose
+    two Choleskys per proposal are 385-dim here, so a whole sweep of a neuron costs it half a second"""
+    _oracle_at_full_size("bernoulli", 128, 5, 50000, rho=0.5, S_w=10.0, nprop=128, nloc=128, seed=23)
 
 
 def test_cfg4_two_neurons_against_the_oracle_at_full_size():
