@@ -74,9 +74,17 @@ struct PglGemmArgs {
     int dim_mode;                              // 0: M = N = d;  1: M = g.M fixed, N = d;  2: M = d, N = g.N fixed;  3: M = min(g.M, d), N = d
     const int* batch_row_off;                  // optional: batch b reads B and writes C from row batch_row_off[b] on (panels stacked per neuron; not for the TRI kinds' skinny rows)
     int pipe;                                  // 1: a rank-k product of the flips / the Cholesky: may take the update pipeline (pgl_update.hip) where that is faster; 2: must
+    // weighted Gram of a small model (one 128 x 128 tile per neuron): K cut into ksplit slices of ks_rows rows, one work item each, whose
+    // products go to Cpart[z][slice] (ldc as C) and are added up in slice order by pgl_gram_split (pgl_gemm.hip)
+    int ksplit; long ks_rows; double* Cpart; long part_stride_z, part_stride_s;
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2, PGL_GEMM_SQUARES = 3 };   // SQUARES: PLAIN on the squared elements of A and B
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
+// X' diag(w_z) X for nz weight columns of a model with D <= 128 columns, K (time) cut into S = ceil(Tp / ks_rows) slices that run as separate work
+// items: part = scratch of nz * part_stride_z doubles, part_stride_z >= S * ldj * ldj.  The slices' sums are added in slice order (a fixed
+// order: the same bits whatever the launch geometry)
+int pgl_gram_split(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ, int accumulate,
+                   long ks_rows, double* part, long part_stride_z, hipStream_t st);
 // the update pipeline (pgl_update.hip): 256 x 128 tiles, DMA-staged, persistent; pgl_launch_gemm routes products marked `pipe` to it
 bool pgl_update_supported(const PglGemmArgs& a);
 int pgl_launch_update(const PglGemmArgs& a, hipStream_t st);

@@ -605,14 +605,18 @@ __device__ __forceinline__ void gram_fine_item(const PglGemmArgs& g, const long 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     const int nz = g.nz_total;
-    const int tile = (int)(w / nz), z = (int)(w % nz);
+    const int z = (int)(w % nz);
+    const int S = g.ksplit > 1 ? g.ksplit : 1;
+    const int sl = (int)((w / nz) % S), tile = (int)(w / nz / S);
     const int tm = isqrt_tri(tile), tn = tile - tm * (tm + 1) / 2;
     const int m0 = tm * 128, n0 = tn * 128;
-    const int nkt = g.K / FK;
+    const long krow0 = S > 1 ? (long)sl * g.ks_rows : 0;                      // this item's slice of K: rows [krow0, krow0 + Ks)
+    const int Ks = S > 1 ? (int)((long)g.K - krow0 < g.ks_rows ? (long)g.K - krow0 : g.ks_rows) : g.K;
+    const int nkt = Ks / FK;
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
     const int frow = lane >> 4, fcol = lane & 15;
-    const double* __restrict__ Ab = g.A;
-    const double* __restrict__ Bb = g.B;
+    const double* __restrict__ Ab = g.A + krow0 * g.lda;
+    const double* __restrict__ Bb = g.B + krow0 * g.ldb;
 
     const int wv = __builtin_amdgcn_readfirstlane(wq);
     const char* gp[5];
@@ -629,7 +633,7 @@ __device__ __forceinline__ void gram_fine_item(const PglGemmArgs& g, const long 
             else { gp[p] = reinterpret_cast<const char*>(Bb + (long)r * g.ldb + cb); gstep[p] = (long)FK * g.ldb * 8; loff[p] = (F_A + r * FSA) * 8; }
         }
         const int dw = wv * 4 + (lane & 3), r = dw >> 1;      // 8 weights = 16 dwords, 4 per wave
-        gp[4] = reinterpret_cast<const char*>(g.W + (long)r * g.ldw + z) + 4 * (dw & 1);
+        gp[4] = reinterpret_cast<const char*>(g.W + (krow0 + r) * g.ldw + z) + 4 * (dw & 1);
         gstep[4] = (long)FK * g.ldw * 8;
         loff[4] = (F_A + F_B) * 8 + wv * 16;
     }
@@ -713,8 +717,8 @@ __device__ __forceinline__ void gram_fine_item(const PglGemmArgs& g, const long 
         }
     }
 
-    double* __restrict__ Cb = g.C + (long)z * g.strideC;
-    const double alpha = g.alpha, beta = g.beta;
+    double* __restrict__ Cb = S > 1 ? g.Cpart + (long)z * g.part_stride_z + (long)sl * g.part_stride_s : g.C + (long)z * g.strideC;
+    const double alpha = S > 1 ? 1.0 : g.alpha, beta = S > 1 ? 0.0 : g.beta;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         double cv[4][4];
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void gram_fine_persistent(PglGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     long* ticket = reinterpret_cast<long*>(smem + (size_t)FST * F_STAGE);
     const int ntm = (g.M + 127) / 128;
-    const long total = (long)ntm * (ntm + 1) / 2 * g.nz_total;
+    const long total = (long)ntm * (ntm + 1) / 2 * g.nz_total * (g.ksplit > 1 ? g.ksplit : 1);
     const long chunk = (total + 7) / 8;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -838,7 +842,7 @@ static int launch_gram_fine(const PglGemmArgs& a0, hipStream_t st) {
     if (int rc = pgl_set_dynamic_lds(reinterpret_cast<const void*>(gram_fine_persistent), F_LDS, attr_set)) return rc;
     const int n_cu = pgl_device_cus(pgl_device());
     const int ntm = (a0.M + 127) / 128;
-    const long total = (long)ntm * (ntm + 1) / 2 * a0.nz_total;
+    const long total = (long)ntm * (ntm + 1) / 2 * a0.nz_total * (a0.ksplit > 1 ? a0.ksplit : 1);
     if (total <= 0) return PGL_OK;
     PglGemmArgs a = a0;
     a.sched = sched_slot(st);
@@ -852,6 +856,43 @@ static int launch_gram_fine(const PglGemmArgs& a0, hipStream_t st) {
 }  // namespace
 
 int* pgl_sched_slot(hipStream_t st) { return sched_slot(st); }
+
+namespace {
+// C[z] (+)= part[z][0] + part[z][1] + ... in slice order, the M x M block
+__global__ __launch_bounds__(256) void sum_k_slices_kernel(const double* __restrict__ part, long stride_z, long stride_s, int S, double* __restrict__ C,
+                                                           long strideC, long ldc, int M, int accumulate) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)M * M) return;
+    const int r = (int)(e / M), c = (int)(e % M), z = blockIdx.y;
+    const double* p = part + (long)z * stride_z + (long)r * ldc + c;
+    double* out = C + (long)z * strideC + (long)r * ldc + c;
+    double acc = accumulate ? *out : 0.0;
+    for (int s = 0; s < S; ++s) acc += p[(long)s * stride_s];
+    *out = acc;
+}
+}  // namespace
+
+int pgl_gram_split(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ, int accumulate,
+                   long ks_rows, double* part, long part_stride_z, hipStream_t st) {
+    PGL_CHECK_ARG(X && W && J && part && Tp > 0 && Tp % 16 == 0 && D > 0 && D <= 128 && nz > 0 && ldj >= D && ldw >= nz && ks_rows >= 16 && ks_rows % 16 == 0);
+    const int S = (int)((Tp + ks_rows - 1) / ks_rows);
+    PGL_CHECK_ARG(S >= 2 && part_stride_z >= (long)S * ldj * ldj);
+    PglGemmArgs a{};
+    a.A = X; a.lda = ldx; a.B = X; a.ldb = ldx;
+    a.C = J; a.ldc = ldj; a.strideC = strideJ;
+    a.W = W; a.ldw = ldw;
+    a.M = D; a.N = D; a.K = Tp;
+    a.a_cols = x_cols & ~1; a.b_cols = x_cols & ~1;
+    a.nbatch = (nz + 1) / 2; a.nz_total = nz;
+    a.alpha = 1.0; a.beta = 0.0; a.tri = 1;
+    a.ksplit = S; a.ks_rows = ks_rows; a.Cpart = part; a.part_stride_z = part_stride_z; a.part_stride_s = ldj * ldj;
+    PGL_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && a.lda % 2 == 0);
+    if (int rc = launch_gram_fine(a, st)) return rc;
+    hipLaunchKernelGGL(sum_k_slices_kernel, dim3((unsigned)(((long)D * D + 255) / 256), nz), dim3(256), 0, st, part, part_stride_z, a.part_stride_s, S, J, strideJ, ldj, D,
+                       accumulate);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
 
 
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {

@@ -358,7 +358,8 @@ def _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z):
     return outs
 
 
-@pytest.mark.parametrize("N,B,T,rho,batch", [(12, 2, 700, 0.5, None), (60, 3, 1500, 0.5, 16), (40, 4, 900, 1.0, 7), (33, 5, 1200, 0.3, 33)])
+@pytest.mark.parametrize("N,B,T,rho,batch", [(12, 2, 700, 0.5, None), (60, 3, 1500, 0.5, 16), (40, 4, 900, 1.0, 7), (33, 5, 1200, 0.3, 33),
+                                             (4, 1, 10000, 0.5, None), (10, 3, 6100, 0.5, 4), (25, 5, 2300, 0.4, 25)])   # (the last three: the fp64 Gram of a small model in time slices)
 def test_sweep_vs_oracle(torch_dev, N, B, T, rho, batch):
     from pyglm_amd.engine import make_draws
     basis, X, Y, rng = _random_problem(N, B, T, seed=N * 7 + B)
@@ -454,12 +455,13 @@ def test_visit_order_and_plain_tableau_agree(torch_dev):
         np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("gram", ["fp64", "int8"])
-def test_sharded_equals_unsharded(torch_dev, gram):
-    """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit (with the fp64 Gram and
-    with the integer Gram, whose neurons travel in groups: scales, planes and residues are per neuron, so the grouping cannot matter)"""
+@pytest.mark.parametrize("gram,T", [("fp64", 600), ("int8", 600), ("fp64", 5000)])
+def test_sharded_equals_unsharded(torch_dev, gram, T):
+    """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit (with the fp64 Gram -- also
+    where a small model's Gram is cut into time slices: their number follows from T and D alone -- and with the integer Gram, whose neurons
+    travel in groups: scales, planes and residues are per neuron, so the grouping cannot matter)"""
     from pyglm_amd.engine import make_draws
-    N, B, T = 11, 2, 600
+    N, B = 11, 2
     basis, X, Y, rng = _random_problem(N, B, T, seed=5)
     kw = dict(rho=0.4, S_w=3.0, mu_w=0.0, mu_b=-1.0, S_b=1.0)
     a = rng.random((N, N)) < 0.5
@@ -467,17 +469,25 @@ def test_sharded_equals_unsharded(torch_dev, gram):
     b = rng.standard_normal(N)
     regs = [orc.Regression(N, B, **kw) for _ in range(N)]
     hyp = _hyp(regs)
-    res = {}
+    res, post = {}, {}
     for (lo, hi) in [(0, N), (0, 5), (5, N)]:
         eng = _engine(N, B, lo, hi, gram=gram)
         eng.add_data(Y, basis=basis)
         perm, u, z = make_draws(9, 2, range(lo, hi), N, N * B)
         sl = slice(lo, hi)
         res[(lo, hi)] = eng.sweep(a[sl], W[sl], b[sl], *[h[sl] for h in hyp], perm, u, z, seed=9, sweep=2)
+        post[(lo, hi)] = [eng.posterior(n - lo)[0][:N * B, :N * B] for n in ((0, 7) if (lo, hi) == (0, N) else (0,) if lo == 0 else (7,))]
     full = res[(0, N)]
     for k in range(4):
         joined = np.concatenate([res[(0, 5)][k], res[(5, N)][k]])
-        np.testing.assert_array_equal(joined, full[k])
+        if T == 600 or k == 0:
+            np.testing.assert_array_equal(joined, full[k])
+        else:       # a long recording: the border sums X' omega are added in time slices whose number follows the shard's size (pgl_sweep.hip)
+            np.testing.assert_allclose(joined, full[k], rtol=1e-9, atol=1e-11)
+    # the likelihood Gram itself (+ the prior blocks) is the same to the last bit: the slices of a small model's Gram do not follow the shard
+    low = np.tril(np.ones((N * B, N * B), dtype=bool))
+    np.testing.assert_array_equal(post[(0, 5)][0][low], post[(0, N)][0][low])
+    np.testing.assert_array_equal(post[(5, N)][0][low], post[(0, N)][1][low])
 
 
 @pytest.mark.parametrize("N,B,T,rho", [(1, 3, 40, 0.5), (2, 1, 5, 0.5), (20, 10, 333, 0.5), (7, 32, 200, 0.6), (3, 2, 17, 0.0), (73, 1, 300, 1.0),
@@ -680,3 +690,37 @@ def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev):
     flips_few = (res[0]["few_a"] != res[0]["many_a"]).sum()
     assert flips_few > 0            # (the two regimes are different chains)
 
+
+
+@pytest.mark.parametrize("N,B,T,nds", [(4, 1, 10000, 1), (9, 3, 4100, 2), (24, 5, 33000, 1), (12, 10, 2048, 1)])
+def test_small_model_gram_in_time_slices(torch_dev, N, B, T, nds):
+    """pgl_sweep cuts the fp64 Gram of a small model (D <= 128: one tile per neuron) into time slices that run as separate work items and are
+    added in slice order (pgl_gram_split): the posterior system against NumPy with the GPU's own omega, over one and two data sets"""
+    from pyglm_amd.engine import make_draws
+    basis, X, Y, rng = _random_problem(N, B, T, seed=N + T)
+    D = N * B
+    eng = _engine(N, B, gram="fp64")
+    Ts = [T] if nds == 1 else [T - 1500, 1500]
+    t0 = 0
+    for Ti in Ts:
+        eng.add_data(Y[t0:t0 + Ti], X=X[t0:t0 + Ti])
+        t0 += Ti
+    kw = dict(rho=0.5, S_w=4.0, mu_w=0.0, mu_b=-1.5, S_b=2.0)
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.3 * a[:, :, None]
+    b = rng.standard_normal(N) - 1.5
+    perm, u, z = make_draws(5, 0, range(N), N, D)
+    eng.sweep(a, W, b, *_hyp(regs), perm, u, z, seed=5, sweep=0)
+    Xf = X.reshape(T, D)
+    t0 = 0
+    om = []
+    for ds in eng.datasets:
+        om.append(ds.OK[:ds.T, :N].cpu().numpy())
+    om = np.concatenate(om)
+    for n in (0, N - 1):
+        Jg, hg = eng.posterior(n)
+        Jp0, hp0 = regs[n].prior_stats()
+        want = Jp0[:D, :D] + (Xf * om[:, n:n + 1]).T @ Xf
+        low = np.tril(np.ones((D, D), dtype=bool))
+        np.testing.assert_allclose(Jg[:D, :D][low], want[low], rtol=1e-11, atol=1e-11 * np.abs(want).max())
