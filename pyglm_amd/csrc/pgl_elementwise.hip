@@ -47,6 +47,9 @@ struct PgLlArgs {
     uint64_t seed, sweep, neuron0, elem0;
 };
 
+// one time bin's term of the log-likelihood (regression.py:491-494); one function for both kernels below, so that they round alike
+__device__ __forceinline__ double pg_ll_term(double logc, double a, double b, double psi) { return logc + a * psi - b * log1p(exp(psi)); }
+
 __global__ __launch_bounds__(256) void pg_loglik_kernel(PgLlArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + lane;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void pg_loglik_kernel(PgLlArgs g) {
             }
             double a = y, b = 1.0, logc = 0.0;
             if (g.obs == 1) { b = y + g.xi; logc = lgamma(y + g.xi) - lgamma(y + 1.0) - lgamma(g.xi); }
-            ll += logc + a * psi - b * log1p(exp(psi));
+            ll += pg_ll_term(logc, a, b, psi);
             if (g.Kappa) g.Kappa[(long)t * g.ldk + n] = a - 0.5 * b;
             if (g.Omega) g.Omega[(long)t * g.ldo + n] = pgl_pg_draw(b, psi, g.seed, stream, g.elem0 + (uint64_t)t);
         }
@@ -79,6 +82,45 @@ __global__ __launch_bounds__(256) void pg_loglik_kernel(PgLlArgs g) {
     red[wave][lane] = ll;
     __syncthreads();
     if (wave == 0 && n < g.nloc) g.llpart[(long)blockIdx.x * g.nloc + n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// The same for a NARROW shard (fewer than 64 local neurons: a small model, BASELINE configs[0]): with a lane per neuron most lanes would idle
+// and every busy one walk 16 time bins one after the other (0.37 of that sweep's 1.0 ms of GPU time at N = 4).  Here the block's
+// PGLL_ROWS x nloc cells are dealt to its 256 threads, each cell's log-likelihood term goes to LDS, and then thread (wave, neuron) adds ITS rows'
+// terms in the order the kernel above adds them -- the same numbers in the same order: the same log-likelihood to the last bit, whatever the shard.
+__global__ __launch_bounds__(256) void pg_loglik_narrow_kernel(PgLlArgs g) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = g.nloc;                                    // < 64
+    const int t0 = blockIdx.x * PGLL_ROWS;
+    __shared__ double term[PGLL_ROWS][64];
+    __shared__ double red[4][64];
+    for (int c = tid; c < PGLL_ROWS * nl; c += 256) {
+        const int r = c / nl, n = c - r * nl, t = t0 + r;
+        double v = 0.0;
+        if (t < g.T) {
+            const double bn = g.bias ? g.bias[n] : 0.0;
+            const uint64_t stream = ((uint64_t)g.sweep << 32) | (uint64_t)(uint32_t)(g.neuron0 + n);
+            const double psi = g.Psi[(long)t * g.ldpsi + n] + bn;
+            g.Psi[(long)t * g.ldpsi + n] = psi;
+            const double y = g.Y[(long)t * g.ldy + n];
+            double a = y, b = 1.0, logc = 0.0;
+            if (g.obs == 1) { b = y + g.xi; logc = lgamma(y + g.xi) - lgamma(y + 1.0) - lgamma(g.xi); }
+            v = pg_ll_term(logc, a, b, psi);
+            if (g.Kappa) g.Kappa[(long)t * g.ldk + n] = a - 0.5 * b;
+            if (g.Omega) g.Omega[(long)t * g.ldo + n] = pgl_pg_draw(b, psi, g.seed, stream, g.elem0 + (uint64_t)t);
+        }
+        term[r][n] = v;
+    }
+    __syncthreads();
+    double ll = 0.0;
+    if (lane < nl)
+        for (int r = wave; r < PGLL_ROWS; r += 4) {
+            if (t0 + r >= g.T) break;
+            ll += term[r][lane];
+        }
+    red[wave][lane] = ll;
+    __syncthreads();
+    if (wave == 0 && lane < nl) g.llpart[(long)blockIdx.x * nl + lane] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 __global__ void colsum_partials_kernel(const double* __restrict__ part, int nblk, int ncol, double* __restrict__ out, int accumulate) {
@@ -229,7 +271,8 @@ int pgl_k_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y
                     uint64_t neuron0, uint64_t elem0, hipStream_t st) {
     PgLlArgs a{Psi, ldpsi, bias, Y, ldy, Omega, ldo, Kappa, ldk, llpart, T, nloc, obs, xi, nullptr, seed, sweep, neuron0, elem0};
     const int nblk = (T + PGLL_ROWS - 1) / PGLL_ROWS;
-    hipLaunchKernelGGL(pg_loglik_kernel, dim3(nblk, (nloc + 63) / 64), dim3(256), 0, st, a);
+    if (nloc < 64 && obs != 2) hipLaunchKernelGGL(pg_loglik_narrow_kernel, dim3(nblk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pg_loglik_kernel, dim3(nblk, (nloc + 63) / 64), dim3(256), 0, st, a);
     PGL_CHECK_LAUNCH();
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, llpart, nblk, nloc, ll_out, accumulate);
     PGL_CHECK_LAUNCH();
