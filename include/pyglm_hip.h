@@ -282,7 +282,8 @@ typedef struct {
                                     * NULL: pgl_i8_colstats per group */
     int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
                                     * this GPU (bench.py scaling_proxy); the state of the others is left alone */
-    /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches */
+    /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches -- in particular not a bit of the result, so
+     * that a shard reproduces its rows of the whole model */
     int all_deterministic;         /* 1: the caller knows every row has rho in {0, 1} (regression.py:153-155): the flip stage is not launched */
     int init_rows_bound;           /* upper bound of 1 + B * (active blocks of any local neuron) BEFORE the sweep */
     int active_rows_bound;         /* upper bound of the same AFTER the flips (only known when all_deterministic) */

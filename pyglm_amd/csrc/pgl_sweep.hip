@@ -187,17 +187,19 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         const pgl_dataset_t& d = s->datasets[i];
         auto m = clk.tic(ST_BORDER, 4.0 * d.T * (D + 1) * nrun);
         // The output is small (2 nloc x (D+1)) and the contraction long (T): with few neurons it is a handful of 128 x 256 tiles -- 6
-        // workgroups at N = 128, 42 on a 128-neuron shard of cfg3 -- each walking all of T.  Then T is cut into S slices, one batch of the
+        // workgroups at N = 128, 42 on a 128-neuron shard of cfg3 -- each walking all of T.  So T is cut into S slices, one batch of the
         // GEMM each, whose partial sums go to the (still unused) J buffer and are added up in slice order by one small kernel.
         // (a prefix run -- nrun < nloc -- contracts the Omega and the Kappa columns of its neurons as two pieces)
         const int npieces = nrun < nloc ? 2 : 1;
         const int Mp = nrun < nloc ? r_up(nrun, 2) : 2 * ldn;
-        const long tiles = (long)((Mp + 127) / 128) * ((D + 1 + 255) / 256) * npieces;
         const long part = (long)2 * ldn * Dp;
-        long S = 2L * pgl_device_cus(pgl_device()) / tiles;
-        if (S > 64) S = 64;
+        // The number of slices follows from T and D ALONE (up to 64 slices of >= 256 bins; for narrow models as many as any shard's J buffer
+        // is sure to hold: ldj^2 / (4 Dp) <= nloc ldj^2 / (2 ldn Dp)), not from how many neurons this shard has: a neuron's sums are then
+        // added up in the same order whatever the sharding, and its whole sweep comes out the same to the last bit on 1 GPU or on 8.
+        long S = 64;
         if (S > d.Tp / 256) S = d.Tp / 256;
-        if (S > (long)nb * strideJ / part) S = (long)nb * strideJ / part;
+        if (S > (long)ldj * ldj / (4L * Dp)) S = (long)ldj * ldj / (4L * Dp);
+        if (S > (long)nb * strideJ / part) S = (long)nb * strideJ / part;          // (a shard in several batches with a cramped buffer: never at D >= 128)
         for (int piece = 0; piece < npieces; ++piece) {
             const double* Ap = d.OK + (long)piece * ldn;                 // columns [0, Mp) of Omega, then of Kappa
             const long crow = (long)piece * ldn * Dp;                    // rows of the border: omega sums, then kappa sums
@@ -278,10 +280,8 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                     auto m = clk.tic(ST_STATS, 8.0 * d.T * D);
                     RC(pgl_k_i8_colmax(d.OK + s0, 2 * ldn, d.T, nbb, ommax + s0, st));
                     const int Mp = r_up(nbb, 2);
-                    const long tiles = (long)((Mp + 127) / 128) * ((D + 255) / 256);
                     const size_t r_bytes = (size_t)(G < nbb ? G : nbb) * np * pgl_k_i8_padded_rows((int)D) * pgl_k_i8_padded_rows((int)D);
-                    long S = 2L * pgl_device_cus(pgl_device()) / tiles;
-                    if (S > 64) S = 64;
+                    long S = 64;                                   // (from T alone, like the border sums: the same norms -- hence scales -- whatever the shard)
                     if (S > d.Tp / 256) S = d.Tp / 256;
                     if (S > (long)(r_bytes / sizeof(double)) / part) S = (long)(r_bytes / sizeof(double)) / part;
                     PglGemmArgs q{};
@@ -373,7 +373,9 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
             const int ck = kmax;
             long rows = s->init_rows_bound > 0 && s->init_rows_bound <= D + 1 ? s->init_rows_bound : D + 1;
             for (int c = 0; (long)c * ck < rows; ++c) {
-                const long left = rows - (long)c * ck;
+                // (the extent of a chunk's launches from D alone: with the hint in it, the blocking of the pivot-block inverse -- and with it the
+                // rounding of the log-odds, in the 13th digit -- followed the most active neuron of the batch, i.e. the sharding)
+                const long left = (D + 1) - (long)c * ck;
                 auto m = clk.tic(ST_FINIT);
                 RC(pgl_k_flip_pivot_chunk(fs, s->act, D + 1, s->na, c, ck, st));
                 RC(pgl_k_flip_apply(fs, 0, (int)(left < ck ? left : ck), -1, st));

@@ -404,8 +404,8 @@ def test_cfg3_whole_model_in_batches_equals_the_oracle_checked_shards():
     """The whole model of the metric's configuration -- 1024 neurons as 4 batches of 256, groups of 8 per product launch: what bench.py times --
     tied to the shard path the oracle checks above: one sweep of the full engine, then the same sweep on two 2-neuron shards (one inside the
     last batch, one straddling the first batch boundary), which must reproduce the full run's rows: every random input is keyed by the global
-    neuron and the integer Gram is exact, so the decisions and the log-likelihoods agree bit for bit; the border sums X'omega are added up in
-    time slices whose number follows the shard's size (pgl_sweep.hip), which moves the log-odds in the ninth digit and the weights in the tenth."""
+    neuron, the integer Gram is exact, and every sum over time is cut into slices whose number follows from T and D alone (pgl_sweep.hip), so
+    EVERYTHING agrees bit for bit -- decisions, log-odds, weights, log-likelihoods: what 8 GPUs would compute is what one computes."""
     import gc
     import torch
     from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
@@ -438,9 +438,9 @@ def test_cfg3_whole_model_in_batches_equals_the_oracle_checked_shards():
         a2, W2, b2, ll2 = sh.sweep(a[sl], W[sl], b[sl], rho[sl], *[h[sl] for h in hyp], perm[sl], u[sl], z[sl], seed=31, sweep=2)
         np.testing.assert_array_equal(a2, a1[sl])
         np.testing.assert_array_equal(ll2, ll1[sl])
-        np.testing.assert_allclose(sh.logodds.cpu().numpy(), lo1[sl], rtol=1e-8, atol=1e-7)
-        np.testing.assert_allclose(W2, W1[sl], rtol=1e-7, atol=1e-9)
-        np.testing.assert_allclose(b2, b1[sl], rtol=1e-7, atol=1e-9)
+        np.testing.assert_array_equal(sh.logodds.cpu().numpy(), lo1[sl])
+        np.testing.assert_array_equal(W2, W1[sl])
+        np.testing.assert_array_equal(b2, b1[sl])
         del sh
         gc.collect()
         torch.cuda.empty_cache()
