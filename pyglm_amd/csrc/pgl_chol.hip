@@ -303,7 +303,7 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     // whole remaining matrix (HBM-bound at rank 128): SP = 4 halves them again, SP = 6 is the measured optimum.
     // (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274; 32 769-dim systems x 4, ms per 8: 6: 1887, 8: 1862)
     static const int SP_env = [] { const int v = pgl_ab_int("PGL_CHOL_SP", 0); return v >= 1 && v <= 8 ? v : 0; }();
-    const int SP = SP_env ? SP_env : (na_max > 8192 ? 8 : 6);
+    const int SP = SP_env ? SP_env : (s.ldact > 8192 ? 8 : 6);         // (from the model's size, not from the hint na_max: a hint must not move a bit of the result)
     bool done = false;
     for (int q0 = 0; q0 < na_max && !done; q0 += SP * NBC) {
         for (int i = 0; i < SP; ++i) {
