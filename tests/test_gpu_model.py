@@ -253,7 +253,7 @@ def test_long_chain_matches_oracle_chain_statistically():
     assert np.abs(A1 - A2).max() < 0.35
 
 
-def _two_rank_worker(rank, world, port, out_path, backend="gloo", force_group=False):
+def _two_rank_worker(rank, world, port, out_path, backend="gloo", force_group=False, T=1200):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -271,7 +271,7 @@ def _two_rank_worker(rank, world, port, out_path, backend="gloo", force_group=Fa
         kw = dict(device_id=torch.device(dev)) if backend == "nccl" else {}
         dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kw)
     np.random.seed(0)
-    N, B, T = 9, 2, 1200
+    N, B = 9, 2
     basis = cosine_basis(B, L=10) / 10
     Y = (np.random.rand(T, N) < 0.2).astype(float)
     model = SparseBernoulliGLM(N, basis=basis, regression_kwargs=dict(S_w=5.0, mu_b=-1.0), seed=11, device=dev)
@@ -333,6 +333,22 @@ def test_two_processes_sharing_the_gpu_equal_one(tmp_path):
     mp.spawn(_two_rank_worker, args=(2, port, two), nprocs=2, join=True)
     a, b = np.load(one), np.load(two)
     assert a["lls"][-1] == a["lls"][-2]
+    for k in a.files:
+        if k == "lls":
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-13)      # sum over neurons in a different grouping
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_on_a_long_recording_equal_one(tmp_path):
+    """the same with T = 9000: the border sums, the small-model Gram and the column norms are then added in time slices -- whose number
+    follows from T and D alone, not from the 5 or 4 neurons a rank holds: still bit for bit"""
+    import torch.multiprocessing as mp
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_two_rank_worker, args=(1, 0, one, "gloo", False, 9000), nprocs=1, join=True)
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), two, "gloo", False, 9000), nprocs=2, join=True)
+    a, b = np.load(one), np.load(two)
     for k in a.files:
         if k == "lls":
             np.testing.assert_allclose(a[k], b[k], rtol=1e-13)      # sum over neurons in a different grouping
