@@ -1,6 +1,6 @@
 #!/bin/bash
 # MFMA-busy, wait and L2 counters of the integer product kernel on the bench's own data (one group of 8 neurons at the cfg3 shape):
-#   [PZERO=1] [PGL_PROBE_LIB=ab3] tools/pmc_i8_busy.sh <tag> ["counter sets"...]   (through gpurun, from the repo root)
+#   [PZERO=1] [PGL_PROBE_LIB=ab] tools/pmc_i8_busy.sh <tag> ["counter sets"...]   (through gpurun, from the repo root)
 #   -> gpurun_out/<tag>_i8busy_*/ + gpurun_out/<tag>_i8busy.txt
 # Separate --pmc passes, --kernel-trace only, the program itself after `--`.
 tag=${1:-r04}${PZERO:+_zero}${PGL_PROBE_LIB:+_$PGL_PROBE_LIB}
