@@ -80,7 +80,7 @@ struct PglGemmArgs {
 };
 enum PglGemmKind { PGL_GEMM_GRAM2 = 0, PGL_GEMM_PLAIN = 1, PGL_GEMM_TRI1 = 2, PGL_GEMM_SQUARES = 3 };   // SQUARES: PLAIN on the squared elements of A and B
 int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st);
-// X' diag(w_z) X for nz weight columns of a model with D <= 128 columns, K (time) cut into S = ceil(Tp / ks_rows) slices that run as separate work
+// X' diag(w_z) X for nz weight columns of a model with D <= 512 columns, K (time) cut into S = ceil(Tp / ks_rows) slices that run as separate work
 // items: part = scratch of nz * part_stride_z doubles, part_stride_z >= S * ldj * ldj.  The slices' sums are added in slice order (a fixed
 // order: the same bits whatever the launch geometry)
 int pgl_gram_split(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ, int accumulate,

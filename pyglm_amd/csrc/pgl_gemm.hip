@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void sum_k_slices_kernel(const double* __restr
 
 int pgl_gram_split(const double* X, long ldx, int x_cols, const double* W, long ldw, int Tp, int D, int nz, double* J, long ldj, long strideJ, int accumulate,
                    long ks_rows, double* part, long part_stride_z, hipStream_t st) {
-    PGL_CHECK_ARG(X && W && J && part && Tp > 0 && Tp % 16 == 0 && D > 0 && D <= 128 && nz > 0 && ldj >= D && ldw >= nz && ks_rows >= 16 && ks_rows % 16 == 0);
+    PGL_CHECK_ARG(X && W && J && part && Tp > 0 && Tp % 16 == 0 && D > 0 && D <= 512 && nz > 0 && ldj >= D && ldw >= nz && ks_rows >= 16 && ks_rows % 16 == 0);
     const int S = (int)((Tp + ks_rows - 1) / ks_rows);
     PGL_CHECK_ARG(S >= 2 && part_stride_z >= (long)S * ldj * ldj);
     PglGemmArgs a{};

@@ -250,14 +250,14 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 const pgl_dataset_t& d = s->datasets[i];
                 if (!d.int8) {
                     auto m = clk.tic(ST_GRAM, (double)nbb * d.T * D * (D + 1));
-                    // A small model (D <= 128: one tile per neuron) with a long recording is a handful of workgroups each walking all of T --
+                    // A small model (a few 128 x 128 tiles per neuron) with a long recording is a handful of workgroups each walking all of T --
                     // BASELINE configs[0]: 4 items, 1.2 of the sweep's 2 ms.  Then T is cut into slices of >= 1024 bins, one work item each,
                     // whose sums land in the flips' (idle) pivot-block buffer G ([nb][kmax][kmax]) and are added in slice order.  The number of
                     // slices follows from T and D alone -- not from the number of neurons -- so a shard gets the bits of the whole.
                     long S = d.Tp / 1024;
                     if (S > (long)kmax * kmax / ((long)ldj * ldj)) S = (long)kmax * kmax / ((long)ldj * ldj);
                     if (S > 32) S = 32;
-                    if (D <= 128 && S >= 2) {
+                    if (D <= 512 && S >= 2) {
                         const long ks = r_up((d.Tp + S - 1) / S, 16);
                         RC(pgl_gram_split(d.X, Dp, Dp, d.OK + s0, 2 * ldn, d.Tp, (int)D, nbb, s->Jbuf, ldj, strideJ, i > 0, ks, s->G, (long)kmax * kmax, st));
                     } else RC(pgl_weighted_gram(d.X, Dp, Dp, d.OK + s0, 2 * ldn, d.Tp, (int)D, nbb, s->Jbuf, ldj, strideJ, i > 0, st));

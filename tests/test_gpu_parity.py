@@ -689,9 +689,9 @@ def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev):
 
 
 
-@pytest.mark.parametrize("N,B,T,nds", [(4, 1, 10000, 1), (9, 3, 4100, 2), (24, 5, 33000, 1), (12, 10, 2048, 1)])
+@pytest.mark.parametrize("N,B,T,nds", [(4, 1, 10000, 1), (9, 3, 4100, 2), (24, 5, 33000, 1), (12, 10, 2048, 1), (40, 5, 6000, 1), (30, 10, 4096, 2)])
 def test_small_model_gram_in_time_slices(torch_dev, N, B, T, nds):
-    """pgl_sweep cuts the fp64 Gram of a small model (D <= 128: one tile per neuron) into time slices that run as separate work items and are
+    """pgl_sweep cuts the fp64 Gram of a small model (D <= 512: a few tiles per neuron) into time slices that run as separate work items and are
     added in slice order (pgl_gram_split): the posterior system against NumPy with the GPU's own omega, over one and two data sets"""
     from pyglm_amd.engine import make_draws
     basis, X, Y, rng = _random_problem(N, B, T, seed=N + T)

@@ -3,6 +3,10 @@
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+import pyglm_amd._lib as _l
+if os.environ.get("PGL_PROBE_LIB"):                 # another build of the library next to the shipped one (lib/libpyglm_hip_<name>.so)
+    _l.LIB_PATH = _l.LIB_PATH.replace("libpyglm_hip.so", "libpyglm_hip_%s.so" % os.environ["PGL_PROBE_LIB"])
 from pyglm_amd.engine import GibbsEngine, make_draws, prior_terms
 N, B, T = (int(x) for x in (sys.argv[1:4] + ["4", "1", "10000"][len(sys.argv) - 1:]))
 rng = np.random.default_rng(0)
