@@ -112,10 +112,13 @@ class PowerWatch(object):
     """samples the GPU's graphics clock and socket power (amdsmi, 5 Hz, ~0.5 ms per sample, on a host thread) while a region runs, so that
     the bench line itself says at which clock and power the roofline number was measured"""
 
-    def __init__(self, pci_bus_id=None, period=0.2):
+    def __init__(self, pci_bus_id=None, period=0.2, index=None):
         """pci_bus_id: PCI address of the GPU being timed (torch.cuda.get_device_properties(i).pci_bus_id etc.): amdsmi enumerates the
-        physical devices, the HIP index counts the visible ones -- the handle is matched by address, and the address goes into the record"""
+        physical devices, the HIP index counts the visible ones -- the handle is matched by address, and the address goes into the record.
+        index: the HIP device index, used only when no address matches (a torch build without the pci_* properties, another address
+        format): the record then says `matched_by: index` and why the address did not match"""
         self.period, self.samples, self._stop, self._thread, self.err, self.bdf = period, [], False, None, None, None
+        self.matched_by, self.note = None, None
         try:
             import amdsmi
             amdsmi.amdsmi_init()
@@ -124,11 +127,17 @@ class PowerWatch(object):
             for h in hs:
                 bdf = str(amdsmi.amdsmi_get_gpu_device_bdf(h)).lower()
                 if pci_bus_id and bdf == pci_bus_id.lower():
-                    self._h, self.bdf = h, bdf
+                    self._h, self.bdf, self.matched_by = h, bdf, "pci"
             if self._h is None:
-                if len(hs) != 1:
-                    raise RuntimeError("no amdsmi device with PCI address %r among %d" % (pci_bus_id, len(hs)))
-                self._h, self.bdf = hs[0], str(amdsmi.amdsmi_get_gpu_device_bdf(hs[0])).lower()
+                seen = [str(amdsmi.amdsmi_get_gpu_device_bdf(h)).lower() for h in hs]
+                self.note = "no amdsmi device with PCI address %r among %s" % (pci_bus_id, seen)
+                if len(hs) == 1:
+                    k = 0
+                elif index is not None and 0 <= index < len(hs):
+                    k = index
+                else:
+                    raise RuntimeError(self.note)
+                self._h, self.bdf, self.matched_by = hs[k], seen[k], "only device" if len(hs) == 1 else "index"
             self._smi = amdsmi
         except Exception as e:          # no amdsmi / no permission / no match: the line then simply carries no clock record
             self._smi, self.err = None, repr(e)
@@ -140,7 +149,11 @@ class PowerWatch(object):
                 p = smi.amdsmi_get_power_info(self._h)
                 c = smi.amdsmi_get_clock_info(self._h, smi.AmdSmiClkType.GFX)
                 w = p.get("current_socket_power", p.get("socket_power"))
-                self.samples.append((time.perf_counter(), float(w), float(c["clk"])))
+                try:        # memory-controller (HBM-side) activity in per cent of the peak bandwidth; "N/A" on parts that do not report it
+                    u = float(smi.amdsmi_get_gpu_activity(self._h)["umc_activity"])
+                except Exception:
+                    u = float("nan")
+                self.samples.append((time.perf_counter(), float(w), float(c["clk"]), u))
             except Exception as e:
                 self.err = repr(e)
                 return
@@ -163,9 +176,86 @@ class PowerWatch(object):
             return {"available": False, "error": self.err}
         w = np.array([x[1] for x in self.samples])
         c = np.array([x[2] for x in self.samples])
-        return {"available": True, "pci_bdf": self.bdf, "samples": len(w), "period_s": self.period, "sclk_mhz_mean": float(c.mean()), "sclk_mhz_min": float(c.min()),
+        u = np.array([x[3] for x in self.samples])
+        u = u[np.isfinite(u)]
+        return {"available": True, "pci_bdf": self.bdf, "matched_by": self.matched_by, "match_note": self.note, "samples": len(w), "period_s": self.period, "sclk_mhz_mean": float(c.mean()), "sclk_mhz_min": float(c.min()),
                 "sclk_mhz_max": float(c.max()), "power_w_mean": float(w.mean()), "power_w_max": float(w.max()),
-                "source": "amdsmi (amdsmi_get_clock_info GFX, amdsmi_get_power_info current_socket_power) sampled over the timed region"}
+                "umc_activity_pct_mean": float(u.mean()) if u.size else None,
+                "source": "amdsmi (amdsmi_get_clock_info GFX, amdsmi_get_power_info current_socket_power, amdsmi_get_gpu_activity umc_activity) sampled "
+                          "over the region"}
+
+
+def box_ubench(seconds_i8=2.0, seconds_f64=1.0):
+    """what the matrix cores of THIS box sustain right now (pgl_ubench_mfma: register-only MFMA loops on every CU, power limiter settled):
+    i8 on random operand bytes in TOP/s, fp64 in TFLOP/s.  Boxes of the pool differ by ~5 % on power-limited kernels; the roofline fractions
+    are quoted against these as well as against the nominal peaks, so that a 2 % kernel gain shows in a driver-run line."""
+    import ctypes
+    from pyglm_amd._lib import call
+    out = {}
+    for kind, key, secs, scale in ((0, "i8_tops", seconds_i8, 1e-12), (1, "f64_tflops", seconds_f64, 1e-12)):
+        r, ms = ctypes.c_double(), ctypes.c_double()
+        try:
+            call("pgl_ubench_mfma", kind, secs, ctypes.byref(r), ctypes.byref(ms), None)
+            out[key], out[key.split("_")[0] + "_ms"] = r.value * scale, ms.value
+        except Exception as e:          # noqa: BLE001
+            out[key], out["error"] = None, repr(e)
+    out["note"] = ("pgl_ubench_mfma right before the timed region: v_mfma_i32_16x16x64_i8 on random operand bytes (8 x 4 blocks per wave, two waves "
+                   "per SIMD) and v_mfma_f64_16x16x4_f64 (8 accumulators, one wave per SIMD), every CU, timed after a settling launch")
+    return out
+
+
+def hbm_side_probe(eng, watch, seconds=3.0):
+    """HBM-side traffic of the integer product kernel, MEASURED IN THIS RUN from the SMU's memory-controller activity (amdsmi umc_activity, per cent
+    of the peak bandwidth): rocprofv3 exposes no HBM / Infinity-Cache-side counter on this pool (FETCH_SIZE counts the cache's hits too).
+    Two legs of `seconds` each, sampled at 20 Hz, the first second dropped (the SMU averages over a window): a 4 GiB fill whose traffic is known
+    (calibration: GB/s per per cent), then product launches on the planes of the last group of the last sweep (its residues are scratch)."""
+    import ctypes
+    import torch
+    from pyglm_amd._lib import call, ptr
+    ds = eng.datasets[0]
+    i8 = eng._i8_scratch
+    if watch is None or watch._smi is None or not getattr(ds, "int8", False) or ds.PA is None or not i8 or i8[6]:
+        return None
+    G, PB, R = i8[2], i8[3], i8[4]
+
+    def leg(fn):
+        fn()
+        torch.cuda.synchronize()
+        watch.period = 0.05
+        watch.start()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0, n = time.perf_counter(), 0
+        e0.record()
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            fn()
+            torch.cuda.synchronize()
+            n += 2
+        e1.record()
+        torch.cuda.synchronize()
+        t_first = watch.samples[0][0] if watch.samples else 0.0
+        watch.samples = [x for x in watch.samples if x[0] - t_first >= 1.0] or watch.samples
+        rec = watch.stop()
+        watch.period = 0.2
+        return e0.elapsed_time(e1) / n, rec
+    try:
+        buf = torch.empty(4 << 30, dtype=torch.uint8, device=eng.dev)
+        ms_fill, rec_fill = leg(lambda: buf.fill_(1))
+        del buf
+        ms_k, rec_k = leg(lambda: call("pgl_i8_gram", ptr(ds.PA), ptr(PB), ptr(R), ds.T, eng.D, G, ds.planes, None))
+        u_fill, u_k = rec_fill.get("umc_activity_pct_mean"), rec_k.get("umc_activity_pct_mean")
+        if not u_fill or u_k is None:
+            return {"available": False, "error": "no umc_activity samples"}
+        gbs_fill = (4 << 30) / (ms_fill * 1e-3) * 1e-9
+        per_pct = gbs_fill / u_fill                    # GB/s per per cent of memory-controller activity (81.9 = 8192 GB/s / 100 on MI355X)
+        gbs_k = per_pct * u_k
+        return {"available": True, "hbm_bytes_per_launch": gbs_k * 1e9 * ms_k * 1e-3, "hbm_gb_per_s": gbs_k, "umc_activity_pct": u_k,
+                "launch_ms": ms_k, "neurons_per_launch": G, "power_w_mean": rec_k.get("power_w_mean"), "sclk_mhz_mean": rec_k.get("sclk_mhz_mean"),
+                "calibration": {"kernel": "fill of 4 GiB", "known_gb_per_s": gbs_fill, "umc_activity_pct": u_fill, "gb_per_s_per_pct": per_pct},
+                "source": "amdsmi umc_activity sampled at 20 Hz over %.0f s of back-to-back pgl_i8_gram launches on this run's own planes (the first "
+                          "second dropped), scaled by a fill of known traffic measured the same way; the SMU's counter, not a rocprofv3 PMC" % seconds}
+    except Exception as e:          # noqa: BLE001
+        return {"available": False, "error": repr(e)}
 
 
 def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8), sweeps=2):
@@ -257,6 +347,10 @@ def main():
                          "then seconds per neuron, labelled extrapolated")
     ap.add_argument("--no-fixed-state", action="store_true",
                     help="skip fixed_state (the sweep after the timed region run twice from the same chain state, once fully instrumented)")
+    ap.add_argument("--no-box-ubench", action="store_true",
+                    help="skip the ~4 s of register-only MFMA loops before the timed region (roofline.box_ubench_tops / frac_vs_this_box)")
+    ap.add_argument("--no-hbm-probe", action="store_true",
+                    help="skip hbm_side (umc_activity sampled over ~6 s of fill / product launches after the timed region)")
     ap.add_argument("--no-scaling-proxy", action="store_true",
                     help="skip scaling_proxy (one rank's shard of a 2 / 4 / 8-GPU run, timed on this GPU; N = 1 only)")
     args = ap.parse_args()
@@ -344,7 +438,7 @@ def main():
 
     props = torch.cuda.get_device_properties(local)
     pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
-    watch = PowerWatch(pci) if rank == 0 else None
+    watch = PowerWatch(pci, index=local) if rank == 0 else None
     # who took part in the collectives: backend, world size and every rank's device (what a multi-GPU record is checked against)
     me = {"rank": rank, "device": "cuda:%d" % local, "name": props.name, "pci": pci}
     ranks_info = [me]
@@ -380,6 +474,7 @@ def main():
 
     for _ in range(args.warmup):
         model.resample_model()
+    ubench = box_ubench() if rank == 0 and not args.no_box_ubench else None
     dt, dt_mine, stages, comm_s, power = timed(args.steps, watched=True)
     stages = {k_: dict(v_, ms=v_["ms"] / args.steps, calls=v_["calls"] / args.steps, work=v_["work"] / args.steps) for k_, v_ in stages.items()}
 
@@ -421,6 +516,9 @@ def main():
                  "top_stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_a.items()},
                  "stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st_b.items()},
                  "stages_ms_note": "flips.init / flips.decide / flips.apply are the pieces of `flips`"}
+
+    # ---- HBM-side traffic of the product kernel from the SMU's memory-controller counter (rank 0; not part of `value`)
+    hbm_side = hbm_side_probe(eng, watch) if rank == 0 and not args.no_hbm_probe else None
 
     # ---- what ONE rank of a 2 / 4 / 8-GPU run does, timed here (the driver's multi-GPU run is the measurement; this is the stand-in a
     # one-GPU box can give): the sweep of the first N/G neurons of this model from its current state (not advanced), twice each
@@ -477,7 +575,11 @@ def main():
                 pmc = json.load(open(pmc_path))
             except Exception:
                 pmc = {}
+        # ... and only while the kernel sources are the ones the counters were taken on: the files record pyglm_amd._lib.source_hash()
+        from pyglm_amd._lib import source_hash
+        src_hash = source_hash()
         pmc_ok = args.config == "cfg3" and world == 1 and (N, B, T) == (1024, 5, 100000)
+        pmc_at_head = pmc.get("int8", {}).get("source_hash") == src_hash
         out = {
             "metric": "Gibbs sweeps/sec (full resample_model)", "value": args.steps / dt, "unit": "sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -487,7 +589,9 @@ def main():
                        "neurons_per_batch": eng.nb},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f64_persistent<2,2,2,weighted,3-stage,DMA> (omega-weighted Gram)", "achieved": achieved,
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
-                         "traffic": None, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None},
+                         "traffic": None, "launches": g["calls"], "avg_launch_ms": (g["ms"] / g["calls"]) if g["calls"] else None,
+                         "box_ubench_tflops": (ubench or {}).get("f64_tflops"),
+                         "frac_vs_this_box": (achieved / ubench["f64_tflops"]) if achieved and ubench and ubench.get("f64_tflops") else None},
             "stages_ms_rank0": {k: round(v["ms"], 3) for k, v in stages.items()},
             "stages_note": "ms per sweep on rank 0 from HIP events inside the timed region (%s; averaged over its %d sweeps); the pieces of the "
                            "flip stage are in fixed_state.stages_ms (the next sweep of the chain, fully instrumented, not part of `value`)"
@@ -506,21 +610,30 @@ def main():
             grp = eng._i8_scratch[2] if eng._i8_scratch else 0
             ach = npl * gi["work"] / (gi["ms"] * 1e-3) * 1e-12
             i8p = pmc.get("int8", {})
-            tr_ok = pmc_ok and i8p.get("planes") == npl and i8p.get("group") == grp
+            tr_ok = pmc_ok and pmc_at_head and i8p.get("planes") == npl and i8p.get("group") == grp
             out["dtype"] = "f64 (likelihood Gram: exact integer arithmetic on %d i8 residue planes, CRT back to f64)" % npl
             out["roofline"] = {"bound": "mfma", "kernel": "i8_gram_kernel (v_mfma_i32_16x16x64_i8; %d residue planes of %d neurons per launch)" % (npl, grp),
                                "achieved": ach, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS,
                                "traffic": i8p.get("hbm_bytes_per_launch") if tr_ok else None,
-                               "traffic_source": "profiles/gram_pmc.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)" if tr_ok else None,
+                               "traffic_source": ("profiles/gram_pmc.json: fabric-side FETCH_SIZE + WRITE_SIZE (Infinity-Cache hits included) from rocprofv3 --pmc "
+                                                  "passes of this command, committed, taken at these kernel sources (source_hash %s); not measured in "
+                                                  "this run -- the HBM side, measured in this run, is hbm_side" % src_hash) if tr_ok else
+                                                 ("null: profiles/gram_pmc.json was taken at other kernel sources (%s, now %s) or another geometry"
+                                                  % (i8p.get("source_hash"), src_hash)),
+                               "hbm_side": hbm_side,
                                "launches": gi["calls"], "avg_launch_ms": gi["ms"] / gi["calls"], "planes": npl,
                                "algorithmic_ops_per_launch": npl * gi["work"] / gi["calls"],
                                "fp64_equivalent_tflops": gi["work"] / (gi["ms"] * 1e-3) * 1e-12,
                                "frac_vs_ubench": ach / UBENCH_I8_MFMA_TOPS, "ubench_tops": UBENCH_I8_MFMA_TOPS,
-                               "power_limited_mfma_only_tops": 4000.0}
+                               "box_ubench_tops": (ubench or {}).get("i8_tops"),
+                               "frac_vs_this_box": (ach / ubench["i8_tops"]) if ubench and ubench.get("i8_tops") else None,
+                               "box_ubench": ubench}
             busy_path = os.path.join(ROOT, "profiles", "i8_busy_pmc.json")
             if tr_ok and os.path.exists(busy_path):
                 try:      # effective clock / MFMA-busy / wait counters of this kernel at this geometry: committed rocprofv3 --pmc passes, NOT measured in this run
-                    out["roofline"]["issue_counters"] = dict(json.load(open(busy_path)), source="profiles/i8_busy_pmc.json (committed; not measured in this run)")
+                    busy = json.load(open(busy_path))
+                    if busy.get("source_hash") == src_hash:
+                        out["roofline"]["issue_counters"] = dict(busy, source="profiles/i8_busy_pmc.json (committed, taken at these kernel sources; not measured in this run)")
                 except Exception:
                     pass
             gp = stage("gram.planes")

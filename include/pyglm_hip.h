@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 9
+#define PGL_ABI_VERSION 10
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -34,8 +34,9 @@ const char* pgl_last_error(void);
 /* out[4*i..4*i+3] = Philox4x32-10(counter = (j | purpose<<24, elem0+i, stream lo, stream hi), key = seed). Test hook. */
 int pgl_philox_words(uint64_t seed, uint32_t purpose, uint32_t j, uint64_t elem0, uint64_t stream, uint32_t* out, size_t n, void* hip_stream);
 
-/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; any real b >= 0: floor(b) <= 64 exact Devroye draws of PG(1, z) plus the sum-of-gammas series for
- * the fractional part only; the series alone for b > 64 -- pgl_rng.h).
+/* out[i] ~ PG(b[i], z[i]) (b == NULL -> 1; any real b >= 0.  1 <= b <= 64 is exact: floor(b) - 1 Devroye draws of PG(1, z) plus one draw of
+ * PG(1 + frac(b), z) from Windle's alternate rejection sampler (floor(b) Devroye draws for an integer b); the truncated sum-of-gammas series
+ * only for b < 1 and b > 64 -- pgl_rng.h).
  * Replaces pypolyagamma.pgdrawvpar(ppgs, n, z, out) at pyglm/regression.py:504-507 (samplers built at :474-477). */
 int pgl_pg_draw(const double* b, const double* z, double* out, size_t len, uint64_t seed, uint64_t stream, uint64_t elem0, void* hip_stream);
 
@@ -299,6 +300,16 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
 int pgl_get_state(const pgl_sweep_t* s, int* a_host, double* W_host, double* b_host, double* ll_host, int* status_host, void* hip_stream);
 const char* pgl_stage_name(int i);
 int pgl_stage_times_collect(pgl_stage_times_t* t);    /* waits for the recorded events and adds them to ms / calls / work */
+
+/* ---- box calibration (diagnostic; nothing on the sampling path calls it) ------------------------------------------------------- */
+/* What the matrix cores of the current device sustain right now: a register-only MFMA loop on every CU for ~`seconds` (a quarter of it
+ * untimed first, so that clocks and the package power limiter settle), timed with HIP events on `stream`; WAITS for the stream.
+ *   kind 0: v_mfma_i32_16x16x64_i8 on random operand bytes (what residue planes look like to the multipliers)  -> *rate_out in op/s
+ *   kind 1: v_mfma_f64_16x16x4_f64                                                                              -> *rate_out in flop/s
+ * (2 per multiply-add).  ms_out (optional, host): duration of the timed launch.  Allocates and frees ~1 MiB of device scratch of its own.
+ * bench.py quotes the product kernel of pyglm/regression.py:251-252 against this number as well as against the nominal peak, because the
+ * boxes of a pool differ by several per cent under the power limit. */
+int pgl_ubench_mfma(int kind, double seconds, double* rate_out, double* ms_out, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -171,6 +171,132 @@ static double pg_draw_one(double z, pg_rng* r) {
     }
 }
 
+/* ------------------------------------------------------------------ PG(h, z) for 1 < h < 2: Windle's "alternate" sampler
+ * Windle, Polson & Scott (2014), "Sampling Polya-Gamma random variates: alternate and approximate techniques" (arXiv 1405.0506), Sec. 3 -- the
+ * exact rejection sampler behind BayesLogit's PolyaGammaAlt for 1 <= h <= 4, which pypolyagamma's hybrid sampler uses for small non-integer
+ * shapes.  Restated from the paper's formulas.  With J*(h, z) = 4 PG(h, 2z):
+ *     density   f(x | h, z) = cosh^h(z) exp(-z^2 x / 2) sum_{n >= 0} (-1)^n a_n(x | h),
+ *               a_n(x | h) = 2^h  Gamma(n + h) / (Gamma(n + 1) Gamma(h))  (2n + h) / sqrt(2 pi x^3)  exp(-(2n + h)^2 / (2x))
+ *     envelope  x <= t:  a_0(x | h)                                           (tilted: an inverse Gaussian(mu = h / z, lambda = h^2) on (0, t])
+ *               x >  t:  (pi/2)^h x^(h-1) exp(-pi^2 x / 8) / Gamma(h)         (tilted: a Gamma(h, rate pi^2/8 + z^2/2) on (t, inf))
+ *     accept    by the alternating partial sums S_n once the a_n decrease (they are unimodal in n).
+ * t = t(h) is where the two envelope pieces cross (2/pi = 0.6366 at h = 1: Devroye's 0.64), tabulated per 0.01 of h: pg_alt_trunc below, made by
+ * tests/golden/make_pg_alt_table.py, which also checks with 60-digit arithmetic that both pieces dominate the density well beyond the switch
+ * point.  Any switch point inside that region gives an EXACT sampler; the crossing gives the highest acceptance rate.
+ * Stream consumption (the device code must match it draw for draw): u -> piece; right piece: (E, u) per trial of the truncated-gamma
+ * rejection; left piece, mu > t: (E, u) per trial of the normal tail + one u per candidate, mu <= t: (N, u) per candidate; then u for the
+ * height under the envelope. */
+static const double pg_alt_trunc[101] = {
+    0.6366, 0.6757, 0.7110, 0.7426, 0.7712, 0.7974, 0.8216, 0.8443, 0.8657, 0.8860,
+    0.9054, 0.9240, 0.9420, 0.9594, 0.9763, 0.9928, 1.0088, 1.0245, 1.0399, 1.0550,
+    1.0699, 1.0845, 1.0989, 1.1131, 1.1271, 1.1410, 1.1547, 1.1683, 1.1817, 1.1950,
+    1.2081, 1.2212, 1.2342, 1.2471, 1.2598, 1.2725, 1.2851, 1.2977, 1.3101, 1.3225,
+    1.3349, 1.3471, 1.3593, 1.3715, 1.3836, 1.3956, 1.4076, 1.4196, 1.4315, 1.4434,
+    1.4552, 1.4670, 1.4788, 1.4905, 1.5021, 1.5138, 1.5254, 1.5370, 1.5486, 1.5601,
+    1.5716, 1.5831, 1.5945, 1.6059, 1.6173, 1.6287, 1.6401, 1.6514, 1.6627, 1.6740,
+    1.6853, 1.6965, 1.7078, 1.7190, 1.7302, 1.7414, 1.7526, 1.7637, 1.7748, 1.7860,
+    1.7971, 1.8082, 1.8193, 1.8303, 1.8414, 1.8524, 1.8635, 1.8745, 1.8855, 1.8965,
+    1.9075, 1.9184, 1.9294, 1.9404, 1.9513, 1.9622, 1.9732, 1.9841, 1.9950, 2.0059,
+    2.0168};
+
+/* regularized upper incomplete gamma Q(a, x), a in [1, 2], x > 0: series below a + 1, continued fraction (modified Lentz) above */
+static double gamma_q(double a, double x) {
+    const double lead = exp(-x + a * log(x) - lgamma(a));
+    if (x < a + 1.0) {
+        double term = 1.0 / a, sum = term;
+        for (int n = 1; n < 500; ++n) {
+            term *= x / (a + n);
+            sum += term;
+            if (term < sum * 1e-17) break;
+        }
+        return 1.0 - lead * sum;
+    }
+    const double tiny = 1e-300;
+    double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, hh = d;
+    for (int i = 1; i < 500; ++i) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2.0;
+        d = an * d + b;
+        if (fabs(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        hh *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return lead * hh;
+}
+
+/* Gamma(shape, rate) restricted to (trunc, inf), shape > 1: Dagpunar's (1978) shifted-exponential rejection */
+static double rng_ltgamma(double shape, double rate, double trunc, pg_rng* r) {
+    const double a = shape, b = rate * trunc, d1 = b - a, d3 = a - 1.0;
+    const double c0 = 0.5 * (d1 + sqrt(d1 * d1 + 4.0 * b)) / b;
+    const double lM = d3 * log(d3 / (1.0 - c0)) - d3;
+    for (;;) {
+        const double x = b + rng_expon(r) / c0;
+        const double u = rng_unif(r);
+        if (log(u) <= d3 * log(x) - x * (1.0 - c0) - lM) return trunc * (x / b);
+    }
+}
+
+/* inverse Gaussian(mu = h / z, lambda = h^2) restricted to (0, t] */
+static double pg_alt_left(double h, double z, double t, pg_rng* r) {
+    if (z * t < h) {            /* mu > t: x = h^2 / G^2 with G a standard normal beyond h / sqrt(t) (Robert 1995), thinned by exp(-z^2 x / 2) */
+        const double c = h / sqrt(t), ar = 0.5 * (c + sqrt(c * c + 4.0));
+        for (;;) {
+            double G;
+            for (;;) {
+                G = c + rng_expon(r) / ar;
+                if (rng_unif(r) <= exp(-0.5 * (G - ar) * (G - ar))) break;
+            }
+            const double X = h * h / (G * G);
+            if (rng_unif(r) <= exp(-0.5 * z * z * X)) return X;
+        }
+    }
+    const double mu = h / z, lam = h * h;
+    for (;;) {                  /* Michael, Schucany & Haas (1976), retried until x <= t */
+        const double N = rng_norm(r), Y = N * N;
+        double X = mu + 0.5 * mu * mu * Y / lam - 0.5 * mu / lam * sqrt(4.0 * mu * lam * Y + mu * mu * Y * Y);
+        if (rng_unif(r) > mu / (mu + X)) X = mu * mu / X;
+        if (X <= t) return X;
+    }
+}
+
+static double pg_alt_a(int n, double x, double h, double coef, double* cn) {      /* a_n(x | h); *cn carries Gamma(n + h) / (Gamma(n + 1) Gamma(h)) */
+    if (n == 0) *cn = 1.0; else *cn *= (n + h - 1.0) / n;
+    const double d = 2.0 * n + h;
+    return coef * *cn * exp(log(d) - 1.5 * log(x) - 0.5 * d * d / x);
+}
+
+static double pg_alt(double h, double zpg, pg_rng* r) {       /* one draw of PG(h, zpg), 1 < h < 2 */
+    const double z = 0.5 * fabs(zpg);
+    int k = (int)floor((h - 1.0) * 100.0);
+    if (k < 0) k = 0;
+    if (k > 100) k = 100;
+    const double t = pg_alt_trunc[k];
+    const double lam = 0.125 * PG_PI * PG_PI + 0.5 * z * z;
+    const double st = sqrt(t), hl2 = h * log(2.0);
+    const double wl = exp(hl2 - h * z + log_pnorm((t * z - h) / st)) + exp(hl2 + h * z + log_pnorm(-(t * z + h) / st));
+    const double wr = exp(h * log(0.5 * PG_PI / lam)) * gamma_q(h, lam * t);
+    const double pr = wr / (wl + wr);
+    const double coef = exp(hl2 - 0.5 * log(2.0 * PG_PI));
+    const double lgh = lgamma(h);
+    for (;;) {
+        const double X = rng_unif(r) < pr ? rng_ltgamma(h, lam, t, r) : pg_alt_left(h, z, t, r);
+        double cn, S = pg_alt_a(0, X, h, coef, &cn), prev = S;
+        const double env = X > t ? exp(h * log(0.5 * PG_PI) + (h - 1.0) * log(X) - 0.125 * PG_PI * PG_PI * X - lgh) : S;
+        const double Y = rng_unif(r) * env;
+        for (int n = 1;; ++n) {
+            const double an = pg_alt_a(n, X, h, coef, &cn);
+            const int dec = an <= prev;
+            prev = an;
+            if (n & 1) { S -= an; if (Y <= S && dec) return 0.25 * X; }
+            else       { S += an; if (Y > S && dec) break; }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ PG(b, z) for real b > 0
  * Sum-of-gammas representation (Polson, Scott & Windle 2013, eq. 2):
  *     omega = 1/(2 pi^2) sum_{k>=1} g_k / ((k - 1/2)^2 + z^2/(4 pi^2)),   g_k ~ Gamma(b, 1) i.i.d.
@@ -178,8 +304,10 @@ static double pg_draw_one(double z, pg_rng* r) {
  * b sum 1/d_k and variance b sum 1/d_k^2 (here the two sums are taken term by term up to k = K + 4000 and closed by their integrals --
  * deliberately NOT the closed forms the device code uses).  Gamma variates: Marsaglia & Tsang (2000), "A simple method for
  * generating gamma variables", ACM TOMS 26, without the squeeze; shape < 1 by the U^(1/shape) boost.
- * PG(b, z) = floor(b) draws of PG(1, z) + PG(frac(b), z) by infinite divisibility; for b > PG_DEVROYE_MAX the whole shape goes through
- * the series (cost independent of b). */
+ * By infinite divisibility: 1 <= b <= PG_DEVROYE_MAX is floor(b) - 1 exact draws of PG(1, z) plus ONE exact draw of PG(1 + frac(b), z) from
+ * the alternate sampler above (floor(b) Devroye draws when b is an integer) -- no approximation for any b in [1, 64], which is where
+ * pypolyagamma's own samplers are exact rejection samplers too.  The truncated series is left for b < 1 (pypolyagamma truncates the same
+ * series there, at 200 terms, uncorrected) and for b > PG_DEVROYE_MAX (cost independent of b). */
 #define PG_SERIES_TERMS 32
 #define PG_DEVROYE_MAX 64
 
@@ -242,8 +370,12 @@ int oracle_pg_draw(const double* b, const double* z, double* out, size_t len,
         if (bi > (double)PG_DEVROYE_MAX) s = pg_series(bi, z[i], &r);
         else if (bi > 0.0) {
             const double fl = floor(bi), frac = bi - fl;
-            for (int k = 0; k < (int)fl; ++k) s += pg_draw_one(z[i], &r);
-            if (frac > 0.0) s += pg_series(frac, z[i], &r);
+            if (fl < 1.0) s = pg_series(frac, z[i], &r);
+            else {
+                const int whole = frac > 0.0 ? (int)fl - 1 : (int)fl;
+                for (int k = 0; k < whole; ++k) s += pg_draw_one(z[i], &r);
+                if (frac > 0.0) s += pg_alt(1.0 + frac, z[i], &r);
+            }
         }
         out[i] = s;
     }

@@ -92,9 +92,10 @@ SIGNATURES = {
     "pgl_stage_times_collect": [ctypes.POINTER(StageTimes)],
     "pgl_active_index": [ctypes.POINTER(CholState), c_p],
     "pgl_sample_weights": [ctypes.POINTER(CholState), c_i, c_p],
+    "pgl_ubench_mfma": [c_i, c_d, ctypes.POINTER(c_d), ctypes.POINTER(c_d), c_p],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 
@@ -123,6 +124,22 @@ def load():
         raise PglError("libpyglm_hip.so ABI version %d != %d (rebuild: make -C pyglm_amd/csrc)" % (lib.pgl_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources of the library -- pyglm_amd/csrc/*.hip, *.h and the Makefile, in name order, plus
+    include/pyglm_hip.h: committed hardware-counter summaries (profiles/*.json) record the hash they were taken at, and bench.py quotes them
+    only while it still matches"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = [os.path.join(src, f) for f in sorted(os.listdir(src)) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "pyglm_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def call(name, *args):

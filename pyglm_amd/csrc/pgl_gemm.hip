@@ -858,12 +858,15 @@ static int launch_gram_fine(const PglGemmArgs& a0, hipStream_t st) {
 int* pgl_sched_slot(hipStream_t st) { return sched_slot(st); }
 
 namespace {
-// C[z] (+)= part[z][0] + part[z][1] + ... in slice order, the M x M block
+// C[z] (+)= part[z][0] + part[z][1] + ... in slice order, the lower 128 x 128 TILES of the M x M block: the split Gram writes only tiles on and
+// below the diagonal (tri = 1), so the tiles above it hold whatever the borrowed scratch held before -- they are neither read nor written here
+// (the unsplit kernel leaves J above the diagonal tiles untouched as well)
 __global__ __launch_bounds__(256) void sum_k_slices_kernel(const double* __restrict__ part, long stride_z, long stride_s, int S, double* __restrict__ C,
                                                            long strideC, long ldc, int M, int accumulate) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)M * M) return;
     const int r = (int)(e / M), c = (int)(e % M), z = blockIdx.y;
+    if (r / 128 < c / 128) return;
     const double* p = part + (long)z * stride_z + (long)r * ldc + c;
     double* out = C + (long)z * strideC + (long)r * ldc + c;
     double acc = accumulate ? *out : 0.0;

@@ -3,8 +3,9 @@
 // Stands where the reference calls the third-party `pypolyagamma.pgdrawvpar`
 // (/root/reference/pyglm/regression.py:501-508; shapes b = b_func(y) are real-valued, :479-489).  PG(1, z): Polson, Scott & Windle
 // (2013) Devroye-style alternating-series sampler (truncation t = 0.64).  PG(b, z) for any b > 0 by infinite divisibility:
-// floor(b) <= 64 EXACT draws of PG(1, z) plus, for the fractional part only (or for the whole of b > 64 -- counts that large are rare and
-// the cost of the exact sum grows with b), the sum-of-gammas representation  omega = 1/(2 pi^2) sum_k g_k / ((k - 1/2)^2 + z^2 / (4 pi^2)),
+// 1 <= b <= 64 EXACTLY -- floor(b) - 1 draws of PG(1, z) plus one draw of PG(1 + frac(b), z) from Windle's alternate sampler (pgl_pg_alt;
+// floor(b) Devroye draws when b is an integer); for b < 1 and for the whole of b > 64 (counts that large are rare and
+// the cost of the exact sum grows with b) the sum-of-gammas representation  omega = 1/(2 pi^2) sum_k g_k / ((k - 1/2)^2 + z^2 / (4 pi^2)),
 // g_k ~ Gamma(b, 1), truncated at 32 terms with the remainder drawn as ONE gamma variate matched to the remainder's exact mean and
 // variance (it carries 0.6 % of the mean; its third cumulant is off by 1e-9 of the total) -- the third-party sampler itself truncates
 // the same series, uncorrected, for b < 1.
@@ -147,6 +148,107 @@ __device__ __forceinline__ double pgl_gamma(double alpha, PglPhilox& r) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PG(h, z) for 1 < h < 2, exactly: the "alternate" rejection sampler of Windle, Polson & Scott (2014, arXiv 1405.0506, Sec. 3).  In the
+// scale x = 4 omega, z <- |z| / 2 the density is  cosh^h(z) e^{-z^2 x / 2} sum_n (-1)^n a_n(x | h)  with
+//     a_n(x | h) = 2^h  Gamma(n + h) / (Gamma(n + 1) Gamma(h))  (2n + h) / sqrt(2 pi x^3)  exp(-(2n + h)^2 / (2x));
+// proposal: below the switch point t(h) the n = 0 term (tilted by e^{-z^2 x / 2}: an inverse Gaussian(h / z, h^2) on (0, t]), above it
+// (pi/2)^h x^(h-1) e^{-pi^2 x / 8} / Gamma(h) (tilted: a Gamma(h, pi^2/8 + z^2/2) on (t, inf)); a candidate is accepted or rejected by the
+// alternating partial sums once the a_n decrease.  t(h) = where the two pieces cross, per 0.01 of h (tests/golden/make_pg_alt_table.py; any
+// value inside the region where both pieces dominate the density gives an exact sampler -- checked there with 60-digit arithmetic).
+// oracle/pg_oracle.c holds the separately written CPU version on the same stream: (u) piece; (E, u) per trial of the truncated gamma /
+// of the normal tail; (u) per inverse-chi-square candidate or (N, u) per inverse-Gaussian candidate; (u) height under the envelope.
+static __device__ const double pgl_pg_alt_trunc[101] = {
+    0.6366, 0.6757, 0.7110, 0.7426, 0.7712, 0.7974, 0.8216, 0.8443, 0.8657, 0.8860,
+    0.9054, 0.9240, 0.9420, 0.9594, 0.9763, 0.9928, 1.0088, 1.0245, 1.0399, 1.0550,
+    1.0699, 1.0845, 1.0989, 1.1131, 1.1271, 1.1410, 1.1547, 1.1683, 1.1817, 1.1950,
+    1.2081, 1.2212, 1.2342, 1.2471, 1.2598, 1.2725, 1.2851, 1.2977, 1.3101, 1.3225,
+    1.3349, 1.3471, 1.3593, 1.3715, 1.3836, 1.3956, 1.4076, 1.4196, 1.4315, 1.4434,
+    1.4552, 1.4670, 1.4788, 1.4905, 1.5021, 1.5138, 1.5254, 1.5370, 1.5486, 1.5601,
+    1.5716, 1.5831, 1.5945, 1.6059, 1.6173, 1.6287, 1.6401, 1.6514, 1.6627, 1.6740,
+    1.6853, 1.6965, 1.7078, 1.7190, 1.7302, 1.7414, 1.7526, 1.7637, 1.7748, 1.7860,
+    1.7971, 1.8082, 1.8193, 1.8303, 1.8414, 1.8524, 1.8635, 1.8745, 1.8855, 1.8965,
+    1.9075, 1.9184, 1.9294, 1.9404, 1.9513, 1.9622, 1.9732, 1.9841, 1.9950, 2.0059,
+    2.0168};
+
+__device__ __forceinline__ double pgl_gamma_q(double a, double x) {        // regularized upper incomplete gamma, 1 <= a <= 2
+    const double lead = exp(a * log(x) - x - lgamma(a));
+    if (x < a + 1.0) {                                                      // series for P
+        double term = 1.0 / a, sum = term;
+        for (int n = 1; n < 500 && term >= sum * 1e-17; ++n) { term *= x / (a + n); sum += term; }
+        return 1.0 - lead * sum;
+    }
+    double b = x + 1.0 - a, c = 1e300, d = 1.0 / b, f = d;                 // continued fraction (modified Lentz)
+    for (int i = 1; i < 500; ++i) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2.0;
+        d = an * d + b;  if (fabs(d) < 1e-300) d = 1e-300;
+        c = b + an / c;  if (fabs(c) < 1e-300) c = 1e-300;
+        d = 1.0 / d;
+        const double del = d * c;
+        f *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return lead * f;
+}
+
+__device__ __forceinline__ double pgl_pg_alt(double h, double zpg, PglPhilox& r) {
+    const double z = 0.5 * fabs(zpg);
+    int k = (int)floor((h - 1.0) * 100.0);
+    k = k < 0 ? 0 : k > 100 ? 100 : k;
+    const double t = pgl_pg_alt_trunc[k], rt = sqrt(t);
+    const double rate = 0.125 * PGL_PI * PGL_PI + 0.5 * z * z;
+    const double h2 = h * 0.69314718055994530942;                                  // h log 2
+    // masses of the two proposal pieces (common factor cosh^h z dropped)
+    const double m_left = exp(h2 - h * z + pgl_log_pnorm((t * z - h) / rt)) + exp(h2 + h * z + pgl_log_pnorm(-(t * z + h) / rt));
+    const double m_right = exp(h * log(0.5 * PGL_PI / rate)) * pgl_gamma_q(h, rate * t);
+    const double p_right = m_right / (m_left + m_right);
+    const double coef = exp(h2 - 0.5 * log(2.0 * PGL_PI)), lgh = lgamma(h);
+    // constants of the two proposal samplers
+    const double gb = rate * t, gd = gb - h, ge = h - 1.0, gc = 0.5 * (gd + sqrt(gd * gd + 4.0 * gb)) / gb;   // truncated gamma (Dagpunar 1978)
+    const double glm = ge * log(ge / (1.0 - gc)) - ge;
+    const bool tail = z * t < h;                                                   // inverse-Gaussian mean h / z beyond t
+    const double nc = h / rt, na = 0.5 * (nc + sqrt(nc * nc + 4.0));               // normal tail beyond nc (Robert 1995)
+    const double mu = tail ? 0.0 : h / z, lam = h * h;
+    for (;;) {
+        double X;
+        if (pgl_unif(r) < p_right) {
+            for (;;) {
+                const double x = gb + pgl_expon(r) / gc;
+                const double u = pgl_unif(r);
+                if (log(u) <= ge * log(x) - x * (1.0 - gc) - glm) { X = t * (x / gb); break; }
+            }
+        } else if (tail) {
+            for (;;) {
+                double G;
+                do { G = nc + pgl_expon(r) / na; } while (pgl_unif(r) > exp(-0.5 * (G - na) * (G - na)));
+                X = lam / (G * G);
+                if (pgl_unif(r) <= exp(-0.5 * z * z * X)) break;
+            }
+        } else {
+            do {
+                const double N = pgl_norm(r), Y = N * N;
+                X = mu + 0.5 * mu * mu * Y / lam - 0.5 * mu / lam * sqrt(4.0 * mu * lam * Y + mu * mu * Y * Y);
+                if (pgl_unif(r) > mu / (mu + X)) X = mu * mu / X;
+            } while (X > t);
+        }
+        const double lx = 1.5 * log(X), ix = 0.5 / X;
+        double cn = 1.0;                                                           // Gamma(n + h) / (Gamma(n + 1) Gamma(h))
+        double S = coef * exp(log(h) - lx - h * h * ix), prev = S;
+        const double env = X > t ? exp(h * log(0.5 * PGL_PI) + ge * log(X) - 0.125 * PGL_PI * PGL_PI * X - lgh) : S;
+        const double Y = pgl_unif(r) * env;
+        for (int n = 1;; ++n) {
+            cn *= (n + ge) / n;
+            const double d = 2.0 * n + h;
+            const double an = coef * cn * exp(log(d) - lx - d * d * ix);
+            const bool dec = an <= prev;
+            prev = an;
+            if (n & 1) { S -= an; if (Y <= S && dec) return 0.25 * X; }
+            else { S += an; if (Y > S && dec) break; }
+        }
+    }
+}
+
 #define PGL_PG_SERIES_TERMS 32
 #define PGL_PG_DEVROYE_MAX 64
 
@@ -179,8 +281,11 @@ __device__ __forceinline__ double pgl_pg_draw(double b, double z, uint64_t seed,
     if (!(b > 0.0)) return 0.0;
     if (b > (double)PGL_PG_DEVROYE_MAX) return pgl_pg_series(b, z, r);
     const double fl = floor(b), frac = b - fl;
+    if (fl < 1.0) return pgl_pg_series(frac, z, r);
+    // exact for every 1 <= b <= 64: whole Devroye draws, and the fractional part as ONE draw of PG(1 + frac, z) from the alternate sampler
+    const int whole = frac > 0.0 ? (int)fl - 1 : (int)fl;
     double s = 0.0;
-    for (int k = 0; k < (int)fl; ++k) s += pgl_pg1(z, r);
-    if (frac > 0.0) s += pgl_pg_series(frac, z, r);
+    for (int k = 0; k < whole; ++k) s += pgl_pg1(z, r);
+    if (frac > 0.0) s += pgl_pg_alt(1.0 + frac, z, r);
     return s;
 }

@@ -350,13 +350,15 @@ class GibbsEngine(object):
         measured on MI355X at T = 50 000 (profiles/r04_small_D_crossover.md): the fp64 kernel takes 2.9e-14 s per multiply-add slot of its
         lower 128-tiles; an item of the integer product (one 320-tile of one plane) 1.9e-8 s on its CU, a launch _i8_rounds item-times for
         its group of neurons; the plane conversion 1.95e-13 s per byte.  Measured, ms per sweep int8 / fp64: D = 320 12.8 / 17.7, D = 500
-        (padded to 640) 33.6 / 33.7, D = 640 41.5 / 56, D = 650 (padded to 960) 64.3 / 79.6, D = 900 95.2 / 165.6."""
+        (padded to 640) 33.6 / 33.7, D = 640 41.5 / 56, D = 650 (padded to 960) 64.3 / 79.6, D = 900 95.2 / 165.6.
+        The group size the model is priced at comes from the WHOLE model (min(64, N) neurons per launch), not from how many neurons this
+        shard or batch holds: the two Gram paths differ in the last bits, so the choice must be the same on 1 GPU and on 8 (a shard of 2
+        neurons of a 128-neuron model takes the integer path like the whole model does, at a launch it does not fill)."""
         if T < self.I8_SMALL_T:
             return False
         nt, nq = -(-self.D // 128), -(-self.D // 320)
         t64 = nt * (nt + 1) // 2 * 128 * 128 * 2.9e-14
-        gmax = min(self.I8_GROUPS[0], self.nb or self.nloc)
-        G = max(g for g in self.I8_GROUPS if g <= max(1, gmax))
+        G = max(g for g in self.I8_GROUPS if g <= max(1, min(self.I8_GROUPS[0], self.N)))
         t8 = self._i8_rounds(G, nq * (nq + 1) // 2, planes) / G * 1.9e-8 + planes * nq * 320 * 1.95e-13
         return t8 < 0.9 * t64
 

@@ -81,6 +81,7 @@ class NonlinearAutoregressiveModel(object):
                 t = t.to(self._comm_dev())
             dist.broadcast(t, 0)
             self.seed = int(t.item())
+        self._adopt_state()
         self.sweeps_done = 0
         self.comm_seconds = 0.0        # wall time this rank has spent inside collectives (all_gather of rows, scalar all_reduce)
         self.collectives = 0           # collectives issued by this rank (one per sweep + one per log_likelihood())
@@ -108,18 +109,33 @@ class NonlinearAutoregressiveModel(object):
                 self._engine = GibbsEngine(self.N, self.B, self.n0, self.n1, device=dev, **kw)
         return self._engine
 
-    # ---- state read-backs (models.py:54-64): row = postsynaptic
+    # ---- chain state: three arrays of the model, of which every regression's (a, W, b) are row views (regression._adopt)
+    def _adopt_state(self):
+        """(re)build the model's state arrays from its regressions and make their a / W / b views of them.  Cheap when nothing changed hands:
+        N identity checks.  A regression that was swapped in from outside (`model.regressions[n] = other`) is adopted here."""
+        N = self.N
+        st = getattr(self, "_st", None)
+        regs = self.regressions
+        if st is not None and all(r._store is not None and r._store[0] is st[0] and r._store[3] == n for n, r in enumerate(regs)):
+            return st
+        st = (np.zeros((N, N), dtype=bool), np.zeros((N, N, self.B)), np.zeros((N, 1)))
+        for n, r in enumerate(regs):
+            r._adopt(st[0], st[1], st[2], n)
+        self._st = st
+        return st
+
+    # ---- state read-backs (models.py:54-64): row = postsynaptic.  Copies, like the reference's np.array([...])
     @property
     def weights(self):
-        return np.array([r.W for r in self.regressions])
+        return self._adopt_state()[1].copy()
 
     @property
     def adjacency(self):
-        return np.array([r.a for r in self.regressions])
+        return self._adopt_state()[0].copy()
 
     @property
     def biases(self):
-        return np.array([r.b for r in self.regressions]).ravel()
+        return self._adopt_state()[2].ravel().copy()
 
     def add_data(self, data, X=None):
         """(models.py:66-80)"""
@@ -144,11 +160,14 @@ class NonlinearAutoregressiveModel(object):
 
     # ---- local <-> global state
     def _local_state(self):
-        regs = self.regressions[self.n0:self.n1]
-        a = np.array([r.a for r in regs]).astype(bool)
-        W = np.array([r.W for r in regs])
-        b = np.array([r.b for r in regs]).reshape(-1)
-        return a, W, b
+        # views, not copies: engine.sweep uploads them before it returns, and the model's arrays are only written after it has
+        A, W, b = self._adopt_state()
+        return A[self.n0:self.n1], W[self.n0:self.n1], b[self.n0:self.n1, 0]
+
+    def _store_rows(self, lo, hi, a, W, b):
+        """rows [lo, hi) of the chain state <- (a, W, b): three array assignments (the regressions' a / W / b are views of these arrays)"""
+        A_, W_, b_ = self._adopt_state()
+        A_[lo:hi], W_[lo:hi], b_[lo:hi, 0] = a, W, np.asarray(b).reshape(-1)
 
     def _gather_rows(self, arr):
         """all_gather of per-neuron rows over the shard axis (ranks may own different counts)"""
@@ -207,14 +226,16 @@ class NonlinearAutoregressiveModel(object):
         import time
         import torch
         dist = _dist()
-        t0 = time.perf_counter()
         nccl = dist.get_backend() == "nccl"
+        if not nccl and packed.is_cuda:
+            # gloo works from host memory, and the copy to the host waits for the whole sweep: it is made in _gather_finish -- after the
+            # host has drawn the next sweep's random inputs (host_overlap) -- and is not counted as time inside the collective
+            return ("deferred", packed)
+        t0 = time.perf_counter()
         counts = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
         maxc = max(hi - lo for lo, hi in counts)
         if nccl and not packed.is_cuda:
             packed = packed.to(self._comm_dev())
-        elif not nccl and packed.is_cuda:
-            packed = packed.cpu()
         if packed.shape[0] < maxc:
             pad = torch.zeros((maxc, packed.shape[1]), dtype=torch.uint8, device=packed.device)
             pad[:packed.shape[0]] = packed
@@ -228,6 +249,8 @@ class NonlinearAutoregressiveModel(object):
     def _gather_finish(self, handle):
         """-> (A, W, b, eta) of ALL neurons as host arrays"""
         import time
+        if handle[0] == "deferred":
+            handle = self._gather_start(handle[1].cpu())         # (the wait for the sweep is the sweep's time, not the collective's)
         t0 = time.perf_counter()
         work, out, counts, maxc, _keep = handle
         work.wait()
@@ -382,8 +405,7 @@ class NonlinearAutoregressiveModel(object):
         if handle:
             self.sweeps_done += 1
             A_all, W_all, b_all, _ = self._gather_finish(handle[0])
-            for n, r in enumerate(self.regressions):
-                r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
+            self._store_rows(0, self.N, A_all, W_all, b_all)
             return
         if gaussian:
             # noise variances (regression.py:433-445): residual sums of squares under the NEW weights from the device, gamma draws
@@ -397,9 +419,9 @@ class NonlinearAutoregressiveModel(object):
                 eta[i] = 1.0 / (make_gamma_draws(self.seed, self.sweeps_done, [self.n0 + i], alpha)[0] * (1.0 / beta))
         self.sweeps_done += 1
         if self._shard_override:
-            for i, r in enumerate(regs):
-                r.a, r.W, r.b = a[i].copy(), W[i].copy(), b[i:i + 1].copy()
-                if gaussian:
+            self._store_rows(self.n0, self.n1, a, W, b)
+            if gaussian:
+                for i, r in enumerate(regs):
                     r.eta = float(eta[i])
             return
         if not exchange:
@@ -408,9 +430,9 @@ class NonlinearAutoregressiveModel(object):
             import torch
             packed = torch.from_numpy(self._pack_rows_host(a, W, b, eta if gaussian else None))
             A_all, W_all, b_all, eta_all = self._gather_finish(self._gather_start(packed))
-        for n, r in enumerate(self.regressions):
-            r.a, r.W, r.b = A_all[n].copy(), W_all[n].copy(), b_all[n:n + 1].copy()
-            if gaussian:
+        self._store_rows(0, self.N, A_all, W_all, b_all)
+        if gaussian:
+            for n, r in enumerate(self.regressions):
                 r.eta = float(eta_all[n])
 
     # ---- chain state (checkpoint / resume; also lets two samplers be run from one state)
@@ -440,6 +462,11 @@ class NonlinearAutoregressiveModel(object):
                 setattr(self, k, copy.deepcopy(state[k]))
         for r in self.regressions:
             r._engine_cache = r._lik_engine_cache = None
+        self._st = None                          # the restored regressions share copies of the state arrays: link the model to those
+        r0 = self.regressions[0]
+        if r0._store is not None and all(r._store is not None and r._store[0] is r0._store[0] for r in self.regressions):
+            self._st = r0._store[:3]
+        self._adopt_state()
         self._draws_ahead = None
 
     def plot(self, *args, **kwargs):
@@ -480,7 +507,7 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
         state = npr.get_state()
         npr.seed((self.seed * 1000003 + self.sweeps_done) % (2 ** 32))      # identical on every rank
         try:
-            net.resample((self.adjacency, self.weights))
+            net.resample(self._adopt_state()[:2])         # (the network only reads them)
         finally:
             npr.set_state(state)
         if hasattr(net, "weight_blocks"):

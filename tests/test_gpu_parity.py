@@ -74,7 +74,7 @@ def _device_pg(b, z, n, seed, stream):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("b", [1.0, 2.0, 7.0, 50.0, 0.3, 2.5, 13.7, 70.5])
+@pytest.mark.parametrize("b", [1.0, 2.0, 7.0, 50.0, 0.3, 1.5, 2.5, 13.7, 70.5])
 def test_device_pg_analytic_checks(torch_dev, b):
     """the DEVICE sampler against known answers, not against its twin in the oracle: mean, variance and the Laplace transform
     E exp(-t w) = (cosh(z/2) / cosh(sqrt((z^2/2 + t)/2)))^b over z in {0, 0.3, 2, 6, 20, 40}, integer and real shapes b"""
@@ -91,7 +91,7 @@ def test_device_pg_analytic_checks(torch_dev, b):
             assert abs(g.mean() - pg_laplace(b, z, t)) < 5 * g.std() / np.sqrt(n), (b, z, t)
 
 
-@pytest.mark.parametrize("b,z", [(1.0, 0.0), (1.0, 6.0), (2.0, 0.3), (7.0, 2.0), (50.0, 20.0), (0.3, 0.0), (2.5, 2.0), (13.7, 40.0)])
+@pytest.mark.parametrize("b,z", [(1.0, 0.0), (1.0, 6.0), (2.0, 0.3), (7.0, 2.0), (50.0, 20.0), (0.3, 0.0), (1.5, 1.0), (2.5, 2.0), (13.7, 40.0)])
 def test_device_pg_ks_against_gamma_series(torch_dev, b, z):
     """Kolmogorov-Smirnov of device draws against the defining sum-of-gammas series (600 terms, NumPy)"""
     from scipy import stats
@@ -105,8 +105,8 @@ def test_device_pg_ks_against_gamma_series(torch_dev, b, z):
 @pytest.mark.parametrize("b", [13.7, 50.0, 170.0])
 @pytest.mark.parametrize("z", [0.0, 2.0, 20.0])
 def test_device_pg_series_branch_on_two_million_draws(torch_dev, b, z):
-    """the series branch of the device sampler (every b > 64, every fractional part: 32 terms + a moment-matched gamma remainder; 13.7 is 13
-    exact draws + the series for 0.7, 50 is exact, 170 the series alone) at
+    """large shapes of the device sampler (13.7 is 12 exact Devroye draws + one exact draw of PG(1.7, z) from the alternate sampler, 50 is
+    exact, 170 the series alone: 32 terms + a moment-matched gamma remainder) at
     n = 2e6 per case: mean, variance and THIRD cumulant against the exact values of the defining series (each within 5 standard errors
     of the sample statistic), and a two-sample Kolmogorov-Smirnov test against an independent sampler of the same series -- 2000 terms,
     gamma variates from torch's generator on the GPU (n = 1e6).  tests/test_oracle_pg.py bounds analytically what the truncation changes
@@ -136,9 +136,32 @@ def test_device_pg_series_branch_on_two_million_draws(torch_dev, b, z):
     assert res.pvalue > 1e-3, (b, z, res)
 
 
+@pytest.mark.parametrize("b", [1.5, 2.5, 13.7, 1.003, 1.997])
+def test_device_pg_alternate_sampler_matches_oracle(torch_dev, b):
+    """shapes with a fractional part in [1, 64] are exact on both sides: floor(b) - 1 Devroye draws + ONE draw of PG(1 + frac, z) from Windle's
+    alternate sampler (pgl_rng.h: pgl_pg_alt; oracle/pg_oracle.c: pg_alt, written separately), on the shared stream: device = oracle at 1e-12
+    but for knife-edge accept/reject decisions (libm vs OCML ulps); regression.py:479-489, 501-508 hand such shapes to pgdrawvpar"""
+    torch = torch_dev
+    from pyglm_amd._lib import call, ptr
+    n = 100000
+    rng = np.random.default_rng(int(b * 1000))
+    z = rng.standard_normal(n) * 4.0
+    z[:6] = [0.0, 1e-12, -40.0, 40.0, 2.0 * (1.0 + (b % 1.0)) / 1.2, 90.0]
+    zd = torch.from_numpy(z).cuda()
+    bd = torch.full((n,), b, dtype=torch.float64, device="cuda:0")
+    out = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, 11, orc.stream_id(6, 2), 3, None)
+    got = out.cpu().numpy()
+    want = orc.pg_draw(np.full(n, b), z, 11, orc.stream_id(6, 2), 3)
+    assert np.all(np.isfinite(got)) and np.all(got > 0)
+    close = np.abs(got - want) <= 1e-12 * np.abs(want)
+    assert close.mean() >= 1 - 2e-4 * max(1.0, b), "only %.6f of draws agree" % close.mean()
+
+
 def test_device_pg_real_shapes_match_oracle(torch_dev):
-    """real-valued shapes on a shared stream: the series branch consumes the stream identically on both sides; the remainder's moments are
-    computed by different formulas (closed form on the device, term-by-term sums in the oracle), hence 1e-8 instead of 1e-12"""
+    """real-valued shapes on a shared stream, every branch mixed: the series branch (b < 1, b > 64) consumes the stream identically on both
+    sides, but the remainder's moments are computed by different formulas (closed form on the device, term-by-term sums in the oracle), hence
+    1e-8 instead of 1e-12"""
     torch = torch_dev
     from pyglm_amd._lib import call, ptr
     n = 60000

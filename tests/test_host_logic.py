@@ -479,11 +479,12 @@ def test_integer_gram_planning_arithmetic():
     assert r(5, 3, 13) == 1.0 and r(1, 5356, 13) == 272.0                                                   # flat lists (ragged groups; configs[4])
 
     def pays(N, B, T, nloc=None):
-        eng = types.SimpleNamespace(D=N * B, nb=None, nloc=nloc or N, I8_SMALL_T=GibbsEngine.I8_SMALL_T, I8_GROUPS=GibbsEngine.I8_GROUPS,
+        eng = types.SimpleNamespace(D=N * B, N=N, nb=None, nloc=nloc or N, I8_SMALL_T=GibbsEngine.I8_SMALL_T, I8_GROUPS=GibbsEngine.I8_GROUPS,
                                     _i8_rounds=GibbsEngine._i8_rounds)
         return GibbsEngine._i8_pays(eng, T)
     assert pays(128, 5, 50000) and pays(130, 5, 50000) and pays(64, 5, 50000) and pays(180, 5, 50000)
     assert not pays(100, 5, 50000)           # D = 500 pads to 640: a tie with the fp64 kernel (33.6 / 33.7 ms per sweep measured)
     assert pays(128, 5, 16384) and not pays(128, 5, 16383) and not pays(128, 5, 9000)            # short data sets keep the fp64 kernel
-    assert not pays(128, 5, 50000, nloc=2)   # two neurons do not fill a launch
+    assert pays(128, 5, 50000, nloc=2) and pays(128, 5, 50000, nloc=16)   # the choice follows the whole model, not the shard: 1 GPU and 8 take the same path
+    assert not pays(2, 320, 50000)           # a model of two neurons does not fill a launch
     assert not pays(32, 5, 50000)            # D = 160: one padded tile against three small fp64 tiles

@@ -111,14 +111,15 @@ def gamma_series_sample(b, z, n, rng, K=600):
     return out / (2 * np.pi ** 2)
 
 
-REAL_B = [0.3, 1.0, 2.0, 2.5, 7.0, 12.0, 13.7, 50.0, 70.5]
+REAL_B = [0.3, 1.0, 1.02, 1.5, 2.0, 2.5, 7.0, 12.0, 13.7, 50.0, 63.99, 70.5]
 Z_GRID = [0.0, 0.3, 2.0, 6.0, 20.0, 40.0]
 
 
 @pytest.mark.parametrize("b", REAL_B)
 def test_pg_real_shape_moments_and_laplace(b):
     """PG(b, z) for real-valued b (regression.py:479-489 hands real shapes to pgdrawvpar): mean, variance and the Laplace transform at
-    two arguments, over z from 0 to 40, for shapes on every branch (series only, exact Devroye sums only, Devroye + series for the fractional part; b > 64 -- the series alone -- in the cumulant tests below)"""
+    two arguments, over z from 0 to 40, for shapes on every branch (b < 1: the series; integers: exact Devroye sums; 1 < b < 64 with a
+    fractional part: Devroye draws + one draw of the alternate sampler; b > 64: the series alone -- also in the cumulant tests below)"""
     n = 120000
     for iz, z in enumerate(Z_GRID):
         om = orc.pg_draw(np.full(n, b), np.full(n, z), seed=31, stream=orc.stream_id(iz, int(b * 10)))
@@ -131,7 +132,7 @@ def test_pg_real_shape_moments_and_laplace(b):
             assert abs(g.mean() - pg_laplace(b, z, t)) < 5 * g.std() / np.sqrt(n), (b, z, t)
 
 
-@pytest.mark.parametrize("b,z", [(0.3, 0.0), (0.3, 6.0), (2.5, 2.0), (13.7, 0.3), (50.0, 20.0)])
+@pytest.mark.parametrize("b,z", [(0.3, 0.0), (0.3, 6.0), (1.05, 1.0), (1.5, 0.0), (1.95, 8.0), (2.5, 2.0), (13.7, 0.3), (50.0, 20.0)])
 def test_pg_real_shape_ks_against_gamma_series(b, z):
     rng = np.random.default_rng(int(b * 100 + z))
     n = 20000
@@ -189,3 +190,69 @@ def test_truncated_series_changes_cumulants_by_parts_per_million_at_most(b, z):
     d = 2 * np.pi ** 2 * ((np.arange(1, 33) - 0.5) ** 2 + c)
     assert 1 - b * np.sum(1 / d) / pg_cumulant(b, z, 1) < (0.07 if z == 20.0 else 0.009)
     assert 1 - b * np.sum(d ** -2.0) / pg_cumulant(b, z, 2) < (5e-4 if z == 20.0 else 2e-6)
+
+
+# ----------------------------------------------------------------------------------------------- the alternate sampler (1 < b < 2), exactly
+def _alt_table_in_c():
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "pg_oracle.c")).read()
+    body = re.search(r"pg_alt_trunc\[101\] = \{(.*?)\};", src, flags=re.S).group(1)
+    return [float(v) for v in body.replace("\n", " ").split(",") if v.strip()]
+
+
+def test_alt_sampler_switch_points_and_envelope():
+    """the table of switch points is where the two proposal pieces cross (regenerated here for a few entries), both pieces dominate the
+    density well beyond the switch point (60-digit arithmetic: any switch point in that region gives an exact sampler), and the device header
+    carries the same table"""
+    import importlib.util
+    import os
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_pg_alt_table", os.path.join(here, "golden", "make_pg_alt_table.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    tab = _alt_table_in_c()
+    assert len(tab) == 101 and abs(tab[0] - 2 / np.pi) < 1e-4 and all(b > a for a, b in zip(tab, tab[1:]))
+    for k in (0, 1, 37, 50, 99, 100):
+        assert abs(tab[k] - float(mk.crossing(mk.mp.mpf(1) + mk.mp.mpf(k) / 100))) < 6e-5, k
+    for h in (1.004, 1.5, 1.996):          # shapes inside a bin use the bin's left edge
+        ml, mr = mk.margins(h, tab[min(100, int((h - 1) * 100))], nl=60, nr=120)
+        assert ml >= 0.0 and mr > 0.0, (h, ml, mr)
+    dev = open(os.path.join(os.path.dirname(here), "pyglm_amd", "csrc", "pgl_rng.h")).read()
+    body = re.search(r"pgl_pg_alt_trunc\[101\] = \{(.*?)\};", dev, flags=re.S).group(1)
+    assert [float(v) for v in body.replace("\n", " ").split(",") if v.strip()] == tab
+
+
+@pytest.mark.parametrize("b,z", [(1.5, 0.0), (1.5, 3.0), (1.07, 0.5), (1.93, 12.0)])
+def test_alt_sampler_against_the_exact_distribution_function(b, z):
+    """one-sample Kolmogorov-Smirnov of 2e5 draws against the EXACT distribution function of PG(b, z): the alternating density series of
+    Windle et al. (in x = 4 omega: cosh^b(z/2) exp(-z^2 x / 8) sum_n (-1)^n a_n(x | b)) integrated with 30-digit arithmetic on a grid, linear
+    in between (the grid is fine enough for 1e-4)"""
+    import mpmath as mp
+    mp.mp.dps = 30
+    h, zz = mp.mpf(b), mp.mpf(z) / 2
+
+    def a_n(n, x):
+        return mp.power(2, h) * mp.gamma(n + h) / (mp.gamma(n + 1) * mp.gamma(h)) * (2 * n + h) / mp.sqrt(2 * mp.pi * x ** 3) * mp.exp(-(2 * n + h) ** 2 / (2 * x))
+
+    def dens(x):
+        s, n = mp.mpf(0), 0
+        while True:
+            t = a_n(n, x)
+            s += (-1) ** n * t
+            n += 1
+            if (n > 8 and t < mp.mpf(10) ** -25 * abs(s)) or n > 2000:
+                break
+        return mp.cosh(zz) ** h * mp.exp(-zz * zz * x / 2) * s
+    n = 200000
+    om = orc.pg_draw(np.full(n, b), np.full(n, z), seed=123, stream=orc.stream_id(5, int(100 * b)))
+    x = 4 * om
+    probs = np.concatenate(([1e-4, 1e-3, 5e-3], np.linspace(0.01, 0.99, 99), [0.995, 0.999, 0.9999]))
+    grid = np.concatenate(([0.0], np.quantile(x, probs), [x.max(), x.max() * 1.5 + 5]))
+    cdf = [0.0]
+    for lo, hi in zip(grid[:-1], grid[1:]):
+        cdf.append(cdf[-1] + float(mp.quad(dens, [max(lo, 1e-9), hi])))
+    assert abs(cdf[-1] - 1.0) < 1e-6
+    res = stats.kstest(x, lambda q: np.interp(q, grid, cdf))
+    assert res.pvalue > 1e-3, res

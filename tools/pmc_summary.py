@@ -39,7 +39,9 @@ def main(dfetch, dwrite, prefix, planes, group, cmd, dhit=None):
     alg = planes * Dq * Kp * (1 + group) + planes * group * Dq * (Dq + 320) // 2
     tiles = (Dq // 320) * (Dq // 320 + 1) // 2
     l2lds = planes * group * tiles * 640 * Kp
-    blk = {"planes": planes, "group": group,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pyglm_amd._lib import source_hash
+    blk = {"planes": planes, "group": group, "source_hash": source_hash(),
            "FETCH_SIZE_raw_KB_per_launch": res["FETCH_SIZE"][0], "FETCH_SIZE_launches_averaged": res["FETCH_SIZE"][1], "FETCH_SIZE_avg_launch_s": res["FETCH_SIZE"][2],
            "WRITE_SIZE_raw_KB_per_launch": res["WRITE_SIZE"][0], "WRITE_SIZE_launches_averaged": res["WRITE_SIZE"][1], "WRITE_SIZE_avg_launch_s": res["WRITE_SIZE"][2],
            "cmd": "rocprofv3 --pmc <C> --kernel-trace --kernel-include-regex i8_gram_kernel --output-format csv -- %s (separate passes for FETCH_SIZE and WRITE_SIZE)" % cmd,
