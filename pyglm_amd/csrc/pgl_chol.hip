@@ -132,6 +132,24 @@ __device__ __forceinline__ void inv_steps(const double (&a)[NBC], double (&x)[NB
         inv_steps<K + 1>(a, x, lane);
     }
 }
+// The factorisation and the inversion as ONE chain of steps: step P of the inverse needs column P of L, which is final after step P of the
+// factorisation, and touches other registers than step P + 1 of the factorisation does -- two dependent chains of cross-lane broadcasts that the
+// scheduler can now interleave (each alone leaves the SIMD waiting on a v_readlane most of the time).  Same operations on the same values
+// as potrf_steps followed by inv_steps: the same bits.
+template <int P>
+__device__ __forceinline__ void potrf_inv_steps(double (&a)[NBC], double (&x)[NBC], int lane, int& bad) {
+    if constexpr (P < NBC) {
+        double d = lane_bcast<P>(a[P]);
+        if (!(d > 0.0)) { bad = 1; d = 1.0; }
+        const double r = sqrt(d), inv = 1.0 / r;
+        a[P] = lane == P ? r : a[P] * inv;
+        potrf_row_update<P, P + 1>(a, a[P]);
+#pragma unroll
+        for (int j = 0; j <= P; ++j) x[j] = lane == P ? x[j] * inv : x[j];
+        inv_row_update<P, 0>(x, a[P], lane > P);
+        potrf_inv_steps<P + 1>(a, x, lane, bad);
+    }
+}
 template <int K>
 __device__ __forceinline__ void hcol_steps(const double (&a)[NBC], double& v, int lane) {
     if constexpr (K < NBC) {
@@ -141,6 +159,7 @@ __device__ __forceinline__ void hcol_steps(const double (&a)[NBC], double& v, in
     }
 }
 
+template <bool MERGED>
 __global__ __launch_bounds__(64) void potrf_diag_kernel(CholArgs g, int q0) {
     const int n = blockIdx.x, lane = threadIdx.x;
     const int na = g.na[n];
@@ -152,7 +171,12 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(CholArgs g, int q0) {
 #pragma unroll
     for (int j = 0; j < NBC; ++j) a[j] = (lane < nb && j <= lane) ? Ag[(long)j * g.ldc + lane] : (j == lane ? 1.0 : 0.0);
     int bad = 0;
-    potrf_steps<0>(a, lane, bad);
+    // X = L^-1 (lower): row `lane` in registers, starting from the identity; built step by step beside the factor
+    double x[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) x[j] = j == lane ? 1.0 : 0.0;
+    if constexpr (MERGED) potrf_inv_steps<0>(a, x, lane, bad);
+    else { potrf_steps<0>(a, lane, bad); inv_steps<0>(a, x, lane); }
 #pragma unroll
     for (int j = 0; j < NBC; ++j)
         if (lane < nb && j <= lane) Ag[(long)j * g.ldc + lane] = a[j];          // U11[j][lane] = L[lane][j]
@@ -164,11 +188,6 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(CholArgs g, int q0) {
         hcol_steps<0>(a, v, lane);
         if (lane < nb) hcol[(long)lane * g.ldc] = v;
     }
-    // X = L^-1 (lower): row `lane` in registers, starting from the identity
-    double x[NBC];
-#pragma unroll
-    for (int j = 0; j < NBC; ++j) x[j] = j == lane ? 1.0 : 0.0;
-    inv_steps<0>(a, x, lane);
     double* Tn = g.Tinv + (long)n * NBC * NBC;
 #pragma unroll
     for (int k = 0; k < NBC; ++k) Tn[k * NBC + lane] = (lane >= k && lane < nb && k < nb) ? x[k] : 0.0;     // Tinv[k][m] = (L^-1)[m][k]
@@ -304,6 +323,7 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     // (full 5121-dim systems x 256, ms: 2: 308, 4: 282, 6: 274, 8: 274; 32 769-dim systems x 4, ms per 8: 6: 1887, 8: 1862)
     static const int SP_env = [] { const int v = pgl_ab_int("PGL_CHOL_SP", 0); return v >= 1 && v <= 8 ? v : 0; }();
     const int SP = SP_env ? SP_env : (s.ldact > 8192 ? 8 : 6);         // (from the model's size, not from the hint na_max: a hint must not move a bit of the result)
+    static const bool merged = pgl_ab_int("PGL_CHOL_MERGED", 1) != 0;      // factor and inverse of a diagonal block as one interleaved chain (-2.4 % of the stage)
     bool done = false;
     for (int q0 = 0; q0 < na_max && !done; q0 += SP * NBC) {
         for (int i = 0; i < SP; ++i) {
@@ -313,7 +333,8 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
                 const int rc = trailing(q0, i * NBC, qi, NBC);          // strip: rows of sub-panel i, columns from its diagonal block
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(s.nb), dim3(64), 0, st, g, qi);
+            if (merged) hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(s.nb), dim3(64), 0, st, g, qi);
+            else hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(s.nb), dim3(64), 0, st, g, qi);
             PGL_CHECK_LAUNCH();
             if (nd - qi - NBC <= 0) { done = true; break; }
             const int rc = panel_solve(qi);
@@ -325,6 +346,9 @@ int pgl_k_chol_sample(const PglCholState& s, int na_max, hipStream_t st) {
     }
     // U (mu + x) = w + z, panel by panel from the last; then the scatter
     const long plane = (long)s.nb * s.ldc;
+    // (the whole backward solve as ONE launch -- a workgroup per 256 rows, panels handed on through flags in device memory -- was built and
+    // measured in round 5: same bits, 118.2 against 112.7 ms per batch for the weight stage at 3 670 active rows; the waiting workgroups hold
+    // the CUs the chain's head needs.  profiles/r05_chol_merged_chain_ab.txt)
     hipLaunchKernelGGL(backsolve_init_kernel, dim3((na_max + 255) / 256, s.nb), dim3(256), 0, st, g);
     PGL_CHECK_LAUNCH();
     for (int pi = (na_max + NBC - 1) / NBC - 1; pi >= 0; --pi) {

@@ -594,6 +594,41 @@ __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
     }
 }
 
+// ------------------------------------------------------------------ the pivot rows / columns from the rank-k update itself (initial sweep)
+// fixup_kernel rewrites the pivot rows and columns after the update -- 512 x (D + 2) entries per neuron and chunk, the column part as
+// scattered 8-byte stores.  The update can produce them itself if the pivot COLUMNS of its two operands are patched first: with
+//     Wt'[t][idx_q] = delta_tq - s_q G[t][q]          Ut'[t][idx_r] = M_DD[t][r] - s_r delta_tr      (all other columns as they are)
+// the product M - Wt'' Ut' gives, because G M_DD = 1 and Wt = G Ut,
+//     row idx_q, other columns c:      M[idx_q][c] - Ut[q][c] + s_q Wt[q][c]            =  s_q Wt[q][c]            (Ut[q][c] IS M[idx_q][c])
+//     other rows i, column idx_r:      M[i][idx_r] - (Wt' M_DD)[i][r] + s_r Wt[r][i]    =  s_r Wt[r][i]
+//     idx_q, idx_r:                    (s_q + s_r) delta_qr - s_q s_r G[q][r]           =  -s_q G[q][r] s_r  +  2 s_q delta_qr
+// i.e. exactly what fixup_kernel writes, but for 2 s_q on the diagonal of the pivot block, which diag_fix_kernel takes off again (an exact
+// operation).  A patch is k x k entries per operand instead of k x (D + 2).  Rounding: a pivot row's entry is now formed as M - M + s Wt inside
+// the accumulator, so its absolute error is that of M's magnitude (1e-16 |M|) instead of Wt's -- the same order for a posterior system.
+__global__ __launch_bounds__(256) void patch_pivot_cols_kernel(FlipArgs g) {
+    const int n = blockIdx.y;
+    const int k = g.d_cnt[n];
+    if (k <= 0) return;
+    const int kp = (k + 15) & ~15;
+    const int* idx = g.d_idx + (long)n * KMAX;
+    const double* sgn = g.d_sign + (long)n * KMAX;
+    const double* Gn = g.G + (long)n * KMAX * KMAX;
+    double* Wt = g.Wt + (long)n * KMAX * g.ldu;
+    double* Ut = g.Ut + (long)n * KMAX * g.ldu;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < kp * k; e += gridDim.x * 256) {
+        const int t = e / k, q = e - t * k;                     // q fastest: the B columns of a block are neighbours in a row of Wt
+        const double sq = sgn[q];
+        Wt[(long)t * g.ldu + idx[q]] = (t == q ? 1.0 : 0.0) - sq * Gn[(long)t * KMAX + q];
+        if (t == q) Ut[(long)t * g.ldu + idx[q]] -= sq;
+    }
+}
+__global__ __launch_bounds__(256) void diag_fix_kernel(FlipArgs g) {
+    const int n = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= g.d_cnt[n]) return;
+    const int i = g.d_idx[(long)n * KMAX + q];
+    g.M[(long)n * g.strideM + (long)i * g.ldj + i] -= 2.0 * g.d_sign[(long)n * KMAX + q];
+}
+
 // ------------------------------------------------------------------ tableau in visit order
 // M[n] = P J[n] P' (lower triangle), P = the neuron's proposal order: position k holds block perm[k]; the bias row D and the
 // potential row D+1 stay last.  Once a window of positions has been proposed its rows are never read again, so the rank-k update after
@@ -784,6 +819,13 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
     w.pipe = 1;
     int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st);
     if (rc) return rc;
+    // full-tableau form (initial sweep): the update writes the pivot rows and columns itself from patched operand columns
+    static const bool patch_ab = pgl_ab_int("PGL_FLIP_PATCH", 1) != 0;
+    const bool patch = r0 == 0 && patch_ab;
+    if (patch) {
+        hipLaunchKernelGGL(patch_pivot_cols_kernel, dim3(64, s.nb), dim3(256), 0, st, g);
+        PGL_CHECK_LAUNCH();
+    }
     PglGemmArgs t{};
     t.A = s.Wt + r0; t.lda = s.ldu; t.strideA = (long)KMAX * s.ldu;
     t.B = s.Ut + r0; t.ldb = s.ldu; t.strideB = (long)KMAX * s.ldu;
@@ -793,7 +835,10 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
     t.pipe = 1;
     rc = pgl_launch_gemm(PGL_GEMM_TRI1, t, st);
     if (rc) return rc;
-    if (r0 == 0) {                   // (trailing form: the pivot rows / columns are dead, nothing to rewrite)
+    if (patch) {
+        hipLaunchKernelGGL(diag_fix_kernel, dim3(KMAX / 256, s.nb), dim3(256), 0, st, g);
+        PGL_CHECK_LAUNCH();
+    } else if (r0 == 0) {            // (trailing form: the pivot rows / columns are dead, nothing to rewrite)
         hipLaunchKernelGGL(fixup_kernel, dim3((Md + GT - 1) / GT, KMAX / GT, s.nb), dim3(256), 0, st, g);
         PGL_CHECK_LAUNCH();
     }

@@ -924,6 +924,10 @@ int pgl_launch_gemm(PglGemmKind kind, const PglGemmArgs& a, hipStream_t st) {
         case PGL_GEMM_PLAIN:
             PGL_CHECK_ARG(a.tri == 0);
             if (a.N <= 128) return launch<2, 2, 1, false>(a, st);     // (the 128 x 128 blocks of the pivot-block inversion: no half-empty 256-wide tile)
+            // products with at most 64 output rows -- the row-panel solves and strip updates of the Cholesky (64-row sub-panels against a remainder
+            // thousands of columns wide) -- on 64 x 256 tiles: the 128-row tile ran half empty there (same multiply-adds per element in the
+            // same order: same bits)
+            if (a.M <= 64) return launch<1, 4, 1, false>(a, st);
             return launch<2, 4, 1, false>(a, st);
         case PGL_GEMM_SQUARES:
             PGL_CHECK_ARG(a.tri == 0 && !a.pipe);

@@ -409,6 +409,13 @@ struct GramArgs {
     int accum;                            // add to the residues already in R (a later time slice of the same product)
     int8_t* Rx;                           // split of the LAST plane into K quarters: quarters 1..3 of neuron g's residues
                                           // go to Rx[g][quarter - 1][Dq][Dq] (i8_crt adds the four); NULL: no split
+#ifdef PGL_AB
+#define PGL_KPARTS(g_) ((g_).kparts)
+#else
+#define PGL_KPARTS(g_) 0                  // the shipped kernel is compiled without the experiment (same code as before it existed)
+#endif
+    int kparts;                           // A/B experiment (-DPGL_AB builds, PGL_I8_KPARTS): > 0 cuts the items of EVERY plane into kparts pieces of K,
+                                          // piece-major within a plane, the pieces of a tile adding up in place in R (see pgl_k_i8_gram); 0: off
 };
 
 __device__ __forceinline__ int isqrt_tri_i(int t) {
@@ -502,17 +509,20 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
         const double x = (double)v;
         return (int)fma(-pq, rint(x * ipq), x);
     };
-    int8_t* R = kpart > 0 ? g.Rx + ((long)gz * 3 + (kpart - 1)) * g.Dq * g.Dq : g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
+    const bool inplace = PGL_KPARTS(g) > 0;                     // every plane in K pieces that add up in place (experiment)
+    int8_t* R = (kpart > 0 && !inplace) ? g.Rx + ((long)gz * 3 + (kpart - 1)) * g.Dq * g.Dq : g.R + ((long)gz * g.np + q) * g.Dq * g.Dq;
     // long data sets: the host launches one pass per chunk of KCH K tiles (the int32 sums cannot overflow within one); a pass adds its
     // residues to the previous passes' through the output bytes.  (A chunk loop in here makes hipcc spill the 400 accumulators.)
     {
         int kc = g.kt0;
         int nk = min(nkt - kc, KCH);
         if (kpart >= 0) {                                  // a quarter of the pass (quarters tile it: the last may be short)
-            const int quarter = (nk + 3) >> 2, kend = kc + nk;
+            const int parts = inplace ? PGL_KPARTS(g) : 4;
+            const int quarter = (nk + parts - 1) / parts, kend = kc + nk;
             kc += kpart * quarter;
             nk = min(quarter, kend - kc);
             if (nk <= 0) {                                 // (only for passes of fewer than 4 K tiles: an empty quarter contributes zero)
+                if (inplace && kpart > 0) return;
                 if (g.kt0 == 0 && !g.accum)
                     for (int e = threadIdx.x; e < BT * BT; e += 256) R[(long)(m0 + e / BT) * g.Dq + n0 + e % BT] = 0;
                 return;
@@ -617,7 +627,7 @@ __device__ __forceinline__ void i8_gram_item_big(const GramArgs& g, const int gz
                         *dst8 = (int8_t)(v & 0xff);          // |.| <= p/2 <= 128; +128 (p = 256 only) wraps to -128, congruent
                     }
         };
-        if (g.kt0 == 0 && !g.accum) store(std::false_type{});
+        if (g.kt0 == 0 && !g.accum && !(inplace && kpart > 0)) store(std::false_type{});
         else store(std::true_type{});
     }
 }
@@ -643,9 +653,10 @@ __global__ __launch_bounds__(256) void i8_gram_kernel(GramArgs g) {
     // therefore cut into four K quarters each (their residues land in four slots that i8_crt adds up: modular sums are exact in any
     // order), taken 32 tiles x one quarter at a time so that co-running items still share their strips: 12 x 136 = 51 x 32 full items and
     // 4 x 136 = 17 x 32 quarter items -- no partial round at cfg3, and never more than a quarter item of imbalance after the last full item.
-    const bool split = npx > 0 && g.Rx != nullptr;
-    const int nfull = ntiles * npx * (split ? g.np - 1 : g.np);
-    const int per_xcd = nfull + (split ? 4 * ntiles * npx : 0);
+    const bool split = npx > 0 && g.Rx != nullptr && PGL_KPARTS(g) == 0;
+    const bool pieces = npx > 0 && PGL_KPARTS(g) > 0;
+    const int nfull = pieces ? 0 : ntiles * npx * (split ? g.np - 1 : g.np);
+    const int per_xcd = pieces ? g.np * PGL_KPARTS(g) * npx * ntiles : nfull + (split ? 4 * ntiles * npx : 0);
     const int total = ntiles * g.np * g.G;                 // (flat list)
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -666,6 +677,10 @@ __global__ __launch_bounds__(256) void i8_gram_kernel(GramArgs g) {
             if (w >= 0) {
                 int tm, tn, gz, q, kpart = -1, tile;
                 if (!npx) { const int pair = w / ntiles; tile = w % ntiles; gz = pair / g.np; q = pair % g.np; }
+                else if (pieces) {                         // plane-major, then the piece of K, then the XCD's neurons, then the tiles
+                    const int per_piece = npx * ntiles, per_plane = PGL_KPARTS(g) * per_piece, r = w % per_plane, r2 = r % per_piece;
+                    q = w / per_plane; kpart = r / per_piece; gz = y + 8 * (r2 / ntiles); tile = r2 % ntiles;
+                }
                 else if (w < nfull) {                      // plane-major, then the XCD's neurons, then the tiles of a plane
                     const int per_plane = npx * ntiles, r = w % per_plane;
                     q = w / per_plane; gz = y + 8 * (r / ntiles); tile = r % ntiles;
@@ -807,7 +822,8 @@ int pgl_k_i8_min_planes(int T) {
 
 long pgl_k_i8_kp(int T) { return pgl_i8_kp(T); }
 // is the last plane of a product over G neurons cut into K quarters (whose residues go to the Rx slots)?  Groups that fill the per-XCD lists only
-static bool pgl_k_i8_split(int G, int nplanes) { return G % 8 == 0 && nplanes >= 2; }
+static int pgl_k_i8_kparts() { static const int v = pgl_ab_int("PGL_I8_KPARTS", 0); return v >= 2 && v <= 16 ? v : 0; }
+static bool pgl_k_i8_split(int G, int nplanes) { return G % 8 == 0 && nplanes >= 2 && pgl_k_i8_kparts() == 0; }
 size_t pgl_k_i8_plane_bytes(int D, int T) {
     const long Dq = pgl_k_i8_padded_rows(D), Kp = pgl_i8_kp(T);
     return (size_t)NP * Dq * Kp;
@@ -931,7 +947,7 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
     static const int sbr_ab = pgl_ab_int("PGL_I8_SBR", 0), sbc_ab = pgl_ab_int("PGL_I8_SBC", 0);
     const int sbr = sbr_ab > 0 ? sbr_ab : (lists ? ntm : SB), sbc = sbc_ab > 0 ? sbc_ab : (lists ? 2 : SB);
     for (int kt0 = 0; kt0 < nkt; kt0 += KCH) {
-        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, sbr, sbc, nkt, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr};
+        GramArgs g{PA, PB, R, Dq, Kp, G, nplanes, sbr, sbc, nkt, kt0, pgl_sched_slot(st), KpA, ka0, accumulate ? 1 : 0, pgl_k_i8_split(G, nplanes) ? Rx : nullptr, lists ? pgl_k_i8_kparts() : 0};
         if (!g.sched) { pgl_set_error("i8 gram: scheduler scratch unavailable"); return PGL_ERR_HIP; }
         hipLaunchKernelGGL(i8_gram_kernel, dim3(grid), dim3(256), BNST * BSTAGE, st, g);
         PGL_CHECK_LAUNCH();

@@ -18,6 +18,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import os                                           # noqa: E402
+import pyglm_amd._lib as _l                         # noqa: E402
+if os.environ.get("PGL_PROBE_LIB"):                 # "ab": lib/libpyglm_hip_ab.so, whose tuning knobs read the environment (PGL_I8_KPARTS ...)
+    _l.LIB_PATH = _l.LIB_PATH.replace("libpyglm_hip.so", "libpyglm_hip_%s.so" % os.environ["PGL_PROBE_LIB"])
 from pyglm_amd.engine import GibbsEngine            # noqa: E402
 from pyglm_amd._lib import call, ptr                # noqa: E402
 from pyglm_amd.utils.basis import cosine_basis      # noqa: E402
