@@ -459,6 +459,7 @@ def main():
         eng.profile = profile
         eng.collect_timings()
         c0 = model.comm_seconds
+        w0, o0, l0 = getattr(eng, "wait_seconds", 0.0), getattr(eng, "overlap_seconds", 0.0), getattr(eng, "launch_seconds", 0.0)
         barrier()
         if watched and watch:
             watch.start()
@@ -470,19 +471,27 @@ def main():
         pw = watch.stop() if (watched and watch) else None
         st = eng.collect_timings()
         eng.profile = False
+        timed.launch = getattr(eng, "launch_seconds", 0.0) - l0
+        timed.host_busy = (mine - (model.comm_seconds - c0) - (getattr(eng, "wait_seconds", 0.0) - w0) - (getattr(eng, "overlap_seconds", 0.0) - o0)
+                           - timed.launch)
         return allmax(mine), mine, st, model.comm_seconds - c0, pw
 
     for _ in range(args.warmup):
         model.resample_model()
     ubench = box_ubench() if rank == 0 and not args.no_box_ubench else None
     dt, dt_mine, stages, comm_s, power = timed(args.steps, watched=True)
+    host_busy, launch_s = timed.host_busy, timed.launch
     stages = {k_: dict(v_, ms=v_["ms"] / args.steps, calls=v_["calls"] / args.steps, work=v_["work"] / args.steps) for k_, v_ in stages.items()}
 
     # per-rank breakdown: wall time, time inside collectives, GPU time of the top-level stages, and what is left (host-only share)
     gpu_ms = sum(v["ms"] for k, v in stages.items() if k in TOP_STAGES)            # per sweep
     mine = {"rank": rank, "neurons": model.n1 - model.n0, "ms_per_step": dt_mine / args.steps * 1e3,
             "collectives_ms_per_step": comm_s / args.steps * 1e3, "gpu_stage_ms_per_step": gpu_ms,
-            "host_only_ms_per_step": max(0.0, dt_mine / args.steps * 1e3 - gpu_ms)}
+            "host_only_ms_per_step": max(0.0, dt_mine / args.steps * 1e3 - gpu_ms),
+            # wall time less the waits for the GPU (pgl_get_state), the waits inside collectives, the host work done while the GPU was busy
+            # (the next sweep's random inputs) and the pgl_sweep call itself (its ~3 000 launches overlap the GPU's work; when several ranks share
+            # one GPU the call also waits for room in the queue): what the host adds to a sweep on this rank
+            "host_busy_ms_per_step": host_busy / args.steps * 1e3, "launch_call_ms_per_step": launch_s / args.steps * 1e3}
     per_rank = [mine]
     if use_dist:
         per_rank = [None] * world

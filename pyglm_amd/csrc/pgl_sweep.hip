@@ -196,10 +196,20 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         // The number of slices follows from T and D ALONE (up to 64 slices of >= 256 bins; for narrow models as many as any shard's J buffer
         // is sure to hold: ldj^2 / (4 Dp) <= nloc ldj^2 / (2 ldn Dp)), not from how many neurons this shard has: a neuron's sums are then
         // added up in the same order whatever the sharding, and its whole sweep comes out the same to the last bit on 1 GPU or on 8.
+        // A narrow model's J buffer holds only a few slices (D = 4: four) -- BASELINE configs[0] then walks 2 500 bins per workgroup, a third
+        // of a millisecond of its 0.8 ms sweep.  Its partial sums go to the flips' pivot-block buffer G instead ([nb][kmax][kmax], idle here),
+        // whose capacity for ANY shard, kmax^2 / (4 Dp), exceeds 64 slices up to D ~ 1000.
         long S = 64;
         if (S > d.Tp / 256) S = d.Tp / 256;
-        if (S > (long)ldj * ldj / (4L * Dp)) S = (long)ldj * ldj / (4L * Dp);
-        if (S > (long)nb * strideJ / part) S = (long)nb * strideJ / part;          // (a shard in several batches with a cramped buffer: never at D >= 128)
+        double* scratch = s->Jbuf;
+        long cap_any = (long)ldj * ldj / (4L * Dp), cap_this = (long)nb * strideJ / part;      // what any shard's buffer holds / what this one's does
+        if (cap_any < S && (long)kmax * kmax / (4L * Dp) > cap_any) {
+            scratch = s->G;
+            cap_any = (long)kmax * kmax / (4L * Dp);
+            cap_this = (long)nb * kmax * kmax / part;
+        }
+        if (S > cap_any) S = cap_any;
+        if (S > cap_this) S = cap_this;            // (a shard in several batches with a cramped buffer: never at D >= 128)
         for (int piece = 0; piece < npieces; ++piece) {
             const double* Ap = d.OK + (long)piece * ldn;                 // columns [0, Mp) of Omega, then of Kappa
             const long crow = (long)piece * ldn * Dp;                    // rows of the border: omega sums, then kappa sums
@@ -208,7 +218,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 PglGemmArgs a{};
                 a.A = Ap; a.lda = 2 * ldn; a.strideA = (long)chunk * a.lda; a.a_cols = Mp;
                 a.B = d.X; a.ldb = Dp; a.strideB = (long)chunk * Dp; a.b_cols = Dp;
-                a.C = s->Jbuf + crow; a.ldc = Dp; a.strideC = part;
+                a.C = scratch + crow; a.ldc = Dp; a.strideC = part;
                 a.M = Mp; a.N = (int)D + 1; a.K = chunk; a.nbatch = (int)S; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
                 RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
                 if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
@@ -218,7 +228,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
             } else RC(pgl_contract_tn(Ap, 2 * ldn, Mp, d.X, Dp, Dp, s->border + crow, Dp, Mp, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
         }
         if (S >= 2) {
-            hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, s->Jbuf, part, (int)S, s->border, i > 0, Dp, (int)D + 1);
+            hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, scratch, part, (int)S, s->border, i > 0, Dp, (int)D + 1);
             PGL_CHECK_LAUNCH();
         }
         clk.toc(m);
@@ -251,12 +261,13 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                 if (!d.int8) {
                     auto m = clk.tic(ST_GRAM, (double)nbb * d.T * D * (D + 1));
                     // A small model (a few 128 x 128 tiles per neuron) with a long recording is a handful of workgroups each walking all of T --
-                    // BASELINE configs[0]: 4 items, 1.2 of the sweep's 2 ms.  Then T is cut into slices of >= 1024 bins, one work item each,
-                    // whose sums land in the flips' (idle) pivot-block buffer G ([nb][kmax][kmax]) and are added in slice order.  The number of
-                    // slices follows from T and D alone -- not from the number of neurons -- so a shard gets the bits of the whole.
-                    long S = d.Tp / 1024;
+                    // BASELINE configs[0]: 4 items, 1.2 of the sweep's 2 ms.  Then T is cut into up to 64 slices of >= 256 bins, one work item
+                    // each, whose sums land in the flips' (idle) pivot-block buffer G ([nb][kmax][kmax]: kmax^2 / ldj^2 slices per neuron --
+                    // 1024 at D = 4, 12 at D = 128, 1 from D = 350) and are added in slice order.  The number of slices follows from T and D
+                    // alone -- not from the number of neurons -- so a shard gets the bits of the whole.
+                    long S = d.Tp / 256;
                     if (S > (long)kmax * kmax / ((long)ldj * ldj)) S = (long)kmax * kmax / ((long)ldj * ldj);
-                    if (S > 32) S = 32;
+                    if (S > 64) S = 64;
                     if (D <= 512 && S >= 2) {
                         const long ks = r_up((d.Tp + S - 1) / S, 16);
                         RC(pgl_gram_split(d.X, Dp, Dp, d.OK + s0, 2 * ldn, d.Tp, (int)D, nbb, s->Jbuf, ldj, strideJ, i > 0, ks, s->G, (long)kmax * kmax, st));

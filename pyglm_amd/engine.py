@@ -7,6 +7,7 @@ PyTorch is used for device memory and streams only; all arithmetic is in libpygl
 """
 import ctypes
 import functools
+import time
 
 import numpy as np
 import torch
@@ -162,6 +163,11 @@ class GibbsEngine(object):
         self._times = None              # pgl_stage_times_t filled by pgl_sweep while `profile` is on
         self._i8_norm = None            # integer Gram: per-batch sums of squares of the columns of omega_n X + the largest omega per neuron
         self._ev = []
+        # host-side accounting of sweep(): seconds blocked waiting for the GPU (pgl_get_state) and seconds of host work done while the GPU was
+        # busy (host_overlap) -- what a rank's wall time has to be cleared of to see its exposed host share (bench.py: host_busy_ms_per_step)
+        self.wait_seconds = 0.0
+        self.overlap_seconds = 0.0
+        self.launch_seconds = 0.0      # inside the pgl_sweep call itself: ~3 000 launches at the headline size (and, when the queue is full, waiting)
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
     def _tic(self, name, work=0.0):
@@ -249,16 +255,15 @@ class GibbsEngine(object):
     def _alloc_shard(self):
         """whole-shard state (all a likelihood-only engine needs besides its data)"""
         N, D, nl = self.N, self.D, self.nloc
-        self.a_dev = self._z(nl, N, dtype=I32)
-        self.W_dev = self._z(nl, D)
-        self.b_dev = self._z(nl)
-        self.status = self._z(nl, dtype=I32)
+        # chain state and per-neuron results live at the head of ONE device buffer, the sweep's inputs behind them (_io_reserve): a sweep
+        # is one host-to-device copy from a pinned staging buffer instead of a dozen small ones
+        self._din = self._hin = self._hout = None
+        self._io_reserve(0)
         self.skip = self._z(nl, dtype=I32)
         self._c0_dense = None
         self.Wt = self._z(self.Dp, self.ldn)          # k-major weights for the activation contraction
         self.bias = self._z(nl)
         self.border = self._z(2 * self.ldn, self.Dp)
-        self.ll = self._z(nl)
         if self.obs == 2:
             # Gaussian observations: omega = 1/eta is constant in t, so X'X is formed once per dataset (add_data) and scaled per sweep
             self.G0 = self._z(self.ldj, self.ldj)
@@ -267,6 +272,45 @@ class GibbsEngine(object):
 
     def _st(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ------------------------------------------------------------------ the sweep's I/O block
+    def _io_state_layout(self):
+        """byte offsets of the state block at the head of the I/O buffer: a (nloc x N int32) | W (nloc x D f64) | b | ll (nloc f64) | status
+        (nloc int32) -> (off_a, off_W, off_b, off_ll, off_status, state_bytes), every piece 16-byte aligned"""
+        nl, N, D = self.nloc, self.N, self.D
+        al = lambda x: (x + 15) // 16 * 16
+        off_a = 0
+        off_W = al(off_a + 4 * nl * N)
+        off_b = al(off_W + 8 * nl * D)
+        off_ll = al(off_b + 8 * nl)
+        off_st = al(off_ll + 8 * nl)
+        return off_a, off_W, off_b, off_ll, off_st, al(off_st + 4 * nl)
+
+    def _io_reserve(self, in_bytes):
+        """make the I/O buffer (device) and its pinned staging twin hold the state block + in_bytes of inputs; a_dev / W_dev / b_dev / ll / status
+        are views of the device buffer's head (kept across a growth: the state is copied over)"""
+        off_a, off_W, off_b, off_ll, off_st, sb = self._io_state_layout()
+        need = sb + int(in_bytes)
+        if self._din is not None and self._din.numel() >= need:
+            return
+        cap = max(need, sb + 4096)
+        cap = cap + cap // 8                                    # head-room: a prior that changes form between sweeps does not reallocate
+        new = torch.zeros(cap, dtype=torch.uint8, device=self.dev)
+        if self._din is not None:
+            new[:sb].copy_(self._din[:sb])
+        self._din = new
+        self._hin = torch.zeros(cap, dtype=torch.uint8).pin_memory()
+        self._hin_np = self._hin.numpy()
+        if self._hout is None:
+            self._hout = torch.zeros(sb, dtype=torch.uint8).pin_memory()
+            self._hout_np = self._hout.numpy()
+        nl, N, D = self.nloc, self.N, self.D
+        self.a_dev = new[off_a:off_a + 4 * nl * N].view(I32).view(nl, N)
+        self.W_dev = new[off_W:off_W + 8 * nl * D].view(F64).view(nl, D)
+        self.b_dev = new[off_b:off_b + 8 * nl].view(F64)
+        self.ll = new[off_ll:off_ll + 8 * nl].view(F64)
+        self.status = new[off_st:off_st + 4 * nl].view(I32)
+        self._sweep_cache = None
 
     # ------------------------------------------------------------------ data
     @_on_device
@@ -585,71 +629,108 @@ class GibbsEngine(object):
         a = np.asarray(a).astype(bool)
         rho = np.asarray(rho, dtype=np.float64)
         det = np.all((rho < 1e-6) | (rho > 1 - 1e-6), axis=1)           # regression.py:153-155 (decided again, per row, on the device)
-        # chain state -> device
-        self.a_dev.copy_(torch.from_numpy(a.astype(np.int32)))
-        self.W_dev.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(nloc, D))))
-        self.b_dev.copy_(torch.from_numpy(np.asarray(b, dtype=np.float64).reshape(nloc)))
+        # chain state + hyper-parameters + random inputs -> ONE pinned staging buffer -> one copy to the device
         label = None
         if isinstance(Jw, BlockPrior):
             label, c0, hw, Jw = Jw.label, Jw.c0_u, Jw.hw_u, Jw.Jw_u        # tables + labels travel; the device gathers c0
-        d = dict(rho=rho, Jw=Jw, hw=hw, Jb=Jb, hb=hb, c0=c0, perm=perm, u=u, z=z)
-        dev = {}
-        for k, v in d.items():
-            arr = np.ascontiguousarray(v, dtype=np.int32 if k == "perm" else np.float64)
-            dev[k] = torch.from_numpy(arr).to(self.dev)
-        dev["label"] = None if label is None else torch.from_numpy(label).to(self.dev)
+        off_a, off_W, off_b, off_ll, off_st, sb = self._io_state_layout()
+        items = [("rho", rho, np.float64), ("Jw", Jw, np.float64), ("hw", hw, np.float64), ("Jb", Jb, np.float64), ("hb", hb, np.float64),
+                 ("c0", c0, np.float64), ("perm", perm, np.int32), ("u", u, np.float64), ("z", z, np.float64)]
+        if label is not None:
+            items.append(("label", label, np.int32))
+        arrs, offs, off = {}, {}, sb
+        for k, v, dt in items:
+            arr = np.ascontiguousarray(v, dtype=dt)
+            arrs[k], offs[k] = arr, off
+            off = (off + arr.nbytes + 15) // 16 * 16
+        self._io_reserve(off - sb)
+        hin = self._hin_np
+        hin[off_a:off_a + 4 * nloc * N].view(np.int32)[:] = a.reshape(-1)
+        hin[off_W:off_W + 8 * nloc * D].view(np.float64)[:] = np.asarray(W, dtype=np.float64).reshape(-1)
+        hin[off_b:off_b + 8 * nloc].view(np.float64)[:] = np.asarray(b, dtype=np.float64).reshape(-1)
+        for k, arr in arrs.items():
+            hin[offs[k]:offs[k] + arr.nbytes] = arr.reshape(-1).view(np.uint8)
+        self._din[:off].copy_(self._hin[:off], non_blocking=True)
+        base = self._din.data_ptr()
+        dp = {k: ctypes.c_void_p(base + o) for k, o in offs.items()}
+        dp.setdefault("label", None)
         self.logodds = torch.empty((nloc, N), dtype=F64, device=self.dev) if self.keep_logodds else None
         if label is not None and (self._c0_dense is None):
             self._c0_dense = self._z(nloc, N)
-        keep = [dev]
-        dsets = (_lib.Dataset * len(self.datasets))()
-        for i, ds in enumerate(self.datasets):
-            ov = None
-            if omega_override is not None:
+        keep = []
+        ovs = []
+        if omega_override is not None:
+            for i, ds in enumerate(self.datasets):
                 ov = torch.from_numpy(np.ascontiguousarray(omega_override[i], dtype=np.float64).reshape(ds.T, nloc)).to(self.dev)
                 keep.append(ov)
-            dsets[i] = _lib.Dataset(ds.T, ds.Tp, ptr(ds.X), ptr(ds.Xt), ptr(ds.Y), ptr(ds.Psi), ptr(ds.OK), ptr(ds.llpart), ds.elem0, int(ds.int8),
-                                    int(getattr(ds, "planes", 0) or 0), ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)), ptr(ov),
-                                    ptr(getattr(ds, "xmax", None)))
-        i8 = self._i8_scratch
+                ovs.append(ov)
         if self.profile and self._times is None:
             self._times = _lib.StageTimes()
             if self.profile is not True:
                 lib = _lib.load()
                 names = [lib.pgl_stage_name(i).decode() for i in range(_lib.NSTAGES)]
                 self._times.mask = sum(1 << names.index(n) for n in self.profile)
+        i8 = self._i8_scratch
+        # the argument block of pgl_sweep: every buffer is persistent, so the struct is built once and only what changes from sweep to sweep
+        # is assigned (the I/O pointers, the hints, the optional outputs)
+        sig = (base, len(self.datasets), id(i8), self.nb, bool(ovs), tuple(int(ds.int8) for ds in self.datasets))
+        if self._sweep_cache is None or self._sweep_cache[0] != sig or ovs:
+            dsets = (_lib.Dataset * len(self.datasets))()
+            for i, ds in enumerate(self.datasets):
+                dsets[i] = _lib.Dataset(ds.T, ds.Tp, ptr(ds.X), ptr(ds.Xt), ptr(ds.Y), ptr(ds.Psi), ptr(ds.OK), ptr(ds.llpart), ds.elem0, int(ds.int8),
+                                        int(getattr(ds, "planes", 0) or 0), ptr(getattr(ds, "sA", None)), ptr(getattr(ds, "PA", None)),
+                                        ptr(ovs[i]) if ovs else None, ptr(getattr(ds, "xmax", None)))
+            sw = _lib.Sweep(N, B, self.n0, nloc, self.nb, self.obs, self.xi, int(self.visit_order), self.planes or 0, i8[2] if i8 else 0,
+                            dsets, len(self.datasets), ptr(self.a_dev), ptr(self.W_dev), ptr(self.b_dev),
+                            None, None, None, None, None, None, None, None, None, None,
+                            ptr(getattr(self, "inv_eta", None)), ptr(getattr(self, "G0", None)),
+                            ptr(self.ll), ptr(self.status), None,
+                            ptr(self.Wt), ptr(self.bias), ptr(self.border), ptr(self.skip), None,
+                            ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
+                            ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
+                            ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
+                            int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, None, 0, 0, 0, 0, 0, None)
+            self._sweep_cache = (sig, sw, dsets)
+        sw = self._sweep_cache[1]
+        if ovs:
+            self._sweep_cache = None             # (the override tensors die with this call)
+        sw.rho, sw.Jw, sw.hw, sw.label, sw.Jb, sw.hb, sw.c0 = dp["rho"], dp["Jw"], dp["hw"], dp["label"], dp["Jb"], dp["hb"], dp["c0"]
+        sw.perm, sw.u, sw.z = dp["perm"], dp["u"], dp["z"]
+        sw.logodds, sw.c0_dense = ptr(self.logodds), ptr(self._c0_dense)
+        sw.i8_norm = ptr(self._i8_norm) if i8 else None
         n_act = int(a.sum(axis=1).max()) if a.size else 0
-        sw = _lib.Sweep(N, B, self.n0, nloc, self.nb, self.obs, self.xi, int(self.visit_order), self.planes or 0, i8[2] if i8 else 0,
-                        dsets, len(self.datasets), ptr(self.a_dev), ptr(self.W_dev), ptr(self.b_dev),
-                        ptr(dev["rho"]), ptr(dev["Jw"]), ptr(dev["hw"]), ptr(dev["label"]), ptr(dev["Jb"]), ptr(dev["hb"]), ptr(dev["c0"]),
-                        ptr(dev["perm"]), ptr(dev["u"]), ptr(dev["z"]), ptr(getattr(self, "inv_eta", None)), ptr(getattr(self, "G0", None)),
-                        ptr(self.ll), ptr(self.status), ptr(self.logodds),
-                        ptr(self.Wt), ptr(self.bias), ptr(self.border), ptr(self.skip), ptr(self._c0_dense),
-                        ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
-                        ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
-                        ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
-                        int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, ptr(self._i8_norm) if i8 else None, int(nrun),
-                        int(det.all()), 1 + B * n_act, (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0,
-                        int(self.flip_single_pass), ctypes.pointer(self._times) if self.profile else None)
+        sw.nrun, sw.all_deterministic = int(nrun), int(det.all())
+        sw.init_rows_bound = 1 + B * n_act
+        sw.active_rows_bound = (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0
+        sw.flip_single_pass = int(self.flip_single_pass)
+        sw.times = ctypes.pointer(self._times) if self.profile else None
+        t_launch = time.perf_counter()
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
+        self.launch_seconds += time.perf_counter() - t_launch
         if after_queue is not None:
             after_queue(self)
         if host_overlap is not None:
+            t_ov = time.perf_counter()
             host_overlap()
-        # state, log-likelihood and flags back (waits for the stream)
-        a_i = np.empty((nloc, N), dtype=np.int32) if readback else None
-        W_new = np.empty((nloc, N, B)) if readback else None
-        b_new = np.empty(nloc) if readback else None
-        ll = np.empty(nloc)
-        status = np.empty(nloc, dtype=np.int32)
-        call("pgl_get_state", ctypes.byref(sw), a_i.ctypes.data if readback else None, W_new.ctypes.data if readback else None,
-             b_new.ctypes.data if readback else None, ll.ctypes.data, status.ctypes.data, st)
+            self.overlap_seconds += time.perf_counter() - t_ov
+        t_wait = time.perf_counter()
+        # state, log-likelihood and flags back into the pinned twin of the state block (pgl_get_state waits for the stream)
+        hout = self._hout_np
+        hp = self._hout.data_ptr()
+        call("pgl_get_state", ctypes.byref(sw), ctypes.c_void_p(hp + off_a) if readback else None, ctypes.c_void_p(hp + off_W) if readback else None,
+             ctypes.c_void_p(hp + off_b) if readback else None, ctypes.c_void_p(hp + off_ll), ctypes.c_void_p(hp + off_st), st)
+        self.wait_seconds += time.perf_counter() - t_wait
+        a_i = hout[off_a:off_a + 4 * nloc * N].view(np.int32).reshape(nloc, N) if readback else None
+        W_new = hout[off_W:off_W + 8 * nloc * D].view(np.float64).reshape(nloc, N, B).copy() if readback else None
+        b_new = hout[off_b:off_b + 8 * nloc].view(np.float64).copy() if readback else None
+        ll = hout[off_ll:off_ll + 8 * nloc].view(np.float64).copy()
+        status = hout[off_st:off_st + 4 * nloc].view(np.int32).copy()
         del keep
         if status.any():
             bad = np.nonzero(status)[0]
             raise np.linalg.LinAlgError("posterior system not positive definite for local neurons %s (flags %s)"
                                         % (bad[:8].tolist(), status[bad[:8]].tolist()))
-        return (a_i.astype(bool) if readback else None), W_new, b_new, self._ll_host_np(ll)
+        return (a_i.astype(bool) if readback else None), W_new, b_new, self._ll_host_np(ll)       # (astype copies out of the staging buffer)
 
     @_on_device
     def packed_state(self):

@@ -44,7 +44,7 @@ def shard_bounds(N, world, rank):
 
 class NonlinearAutoregressiveModel(object):
     """(models.py:8-201) y_n[t] ~ p(f(w_n . x[t])), x = basis-filtered history of all neurons."""
-    DRAW_AHEAD_MIN_SIZE = 1 << 16      # N*N*B above which the next sweep's host draws are made while the GPU is busy
+    DRAW_AHEAD_MIN_SIZE = 0            # N*N*B from which the next sweep's host draws are made while the GPU is busy (every size: a small model's sweep leaves the host idle for most of a millisecond)
 
     def __init__(self, N, regressions, basis=None, B=10, device=None, engine_factory=None, seed=None, engine_kwargs=None, shard=None):
         self.N = N

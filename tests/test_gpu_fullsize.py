@@ -1,6 +1,7 @@
-"""Full-size GPU checks through size-independent properties (the oracle cannot finish these sizes in seconds):
-BASELINE.json configs[1] (N=128, B=5, T=50000) end to end, configs[2]-shaped (D=5120, T=100000) per-kernel identities,
-a maximum-size dense case (D=16384) for the Cholesky path, and configs[4]-shaped (D=32768, T=200000) sweeps with flips."""
+"""GPU checks at BASELINE.json's full sizes: the NumPy oracle itself on the box's host cores where it finishes in a minute or two
+(configs[1] whole: 128 neurons, every flip proposal; two neurons of configs[2] and of configs[3] at their own size), and
+size-independent properties where it cannot (configs[2]-shaped per-kernel identities, a maximum-size dense Cholesky, D = 16384,
+configs[4]-shaped sweeps, D = 32768, T = 200000, against long-double blocks)."""
 import ctypes
 
 import numpy as np
