@@ -345,6 +345,9 @@ def main():
     ap.add_argument("--neurons", type=int, default=None,
                     help="time only the first k neurons of this rank's shard (a config whose shard is hours of work per sweep: cfg5); the line is "
                          "then seconds per neuron, labelled extrapolated")
+    ap.add_argument("--xi", type=float, default=2.0,
+                    help="shape of the negative-binomial model (cfg4): PG(y + xi, psi) draws; a fractional xi takes Windle's alternate sampler for the "
+                         "fractional part (pgl_rng.h), an integer xi Devroye draws only")
     ap.add_argument("--no-fixed-state", action="store_true",
                     help="skip fixed_state (the sweep after the timed region run twice from the same chain state, once fully instrumented)")
     ap.add_argument("--no-box-ubench", action="store_true",
@@ -415,7 +418,7 @@ def main():
     ekw = ekw or None
     if cfg.get("obs") == "negbin":
         Y = np.random.default_rng(1).negative_binomial(2, 0.85, size=(T, N)).astype(np.float64)     # counts, mean 0.35
-        model = NegativeBinomialGLM(N, basis=basis, regression_kwargs=dict(S_w=1.0, mu_b=-2.0, xi=2.0), seed=0, engine_kwargs=ekw)
+        model = NegativeBinomialGLM(N, basis=basis, regression_kwargs=dict(S_w=1.0, mu_b=-2.0, xi=args.xi), seed=0, engine_kwargs=ekw)
     elif cfg.get("obs") == "gaussian":
         rg = np.random.default_rng(1)
         Y = rg.standard_normal((T, N)) + 2.0 * Y                                                      # real-valued activity

@@ -6,7 +6,8 @@
  * call site(s) it replaces (paths relative to /root/reference).  Conventions:
  *   - every pointer is a DEVICE pointer unless marked host; the caller owns every data buffer, the library borrows it
  *     for the call only.  The one thing the library allocates itself: per device, on first use, an 8 KiB ring of work
- *     counters for its persistent launches (pgl_gemm.hip, sched_slot), kept until the process ends;
+ *     counters for its persistent launches (pgl_gemm.hip, sched_slot), kept until the process ends (and, inside the diagnostic
+ *     pgl_ubench_mfma only, 1 MiB of scratch that it frees again before it returns);
  *   - calls act on the CURRENT HIP device (hipSetDevice by the caller); library state (kernel attributes, CU count, the
  *     counter ring) is kept per device, so one process may drive several GPUs;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it;
