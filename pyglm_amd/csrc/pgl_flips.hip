@@ -603,8 +603,12 @@ __global__ __launch_bounds__(256) void fixup_kernel(FlipArgs g) {
 //     other rows i, column idx_r:      M[i][idx_r] - (Wt' M_DD)[i][r] + s_r Wt[r][i]    =  s_r Wt[r][i]
 //     idx_q, idx_r:                    (s_q + s_r) delta_qr - s_q s_r G[q][r]           =  -s_q G[q][r] s_r  +  2 s_q delta_qr
 // i.e. exactly what fixup_kernel writes, but for 2 s_q on the diagonal of the pivot block, which diag_fix_kernel takes off again (an exact
-// operation).  A patch is k x k entries per operand instead of k x (D + 2).  Rounding: a pivot row's entry is now formed as M - M + s Wt inside
-// the accumulator, so its absolute error is that of M's magnitude (1e-16 |M|) instead of Wt's -- the same order for a posterior system.
+// operation).  A patch is k x k entries per operand instead of k x (D + 2): -4.9 % of the initial sweep at BASELINE configs[2], same decisions,
+// same log-likelihood to 15 digits (profiles/r05_flips_pivot_patch_ab.txt).
+// NOT THE DEFAULT (an experiment of the -DPGL_AB build, PGL_FLIP_PATCH=1): the row form cancels exactly (Ut[q][c] IS M[idx_q][c]), but the
+// column form leaves ((1 - M_DD G) Ut)[r][i] behind -- the residual of G as an inverse, which the direct write of s Wt never sees.  On the
+// 16 000-dimensional active systems of configs[4] the final tableau's residual |J_SS M_SS v + v| / |v| went from < 1e-8 to 2.4e-8 (3e-7 on the
+// bias row, whose column of Ut is ten times larger): tests/test_gpu_fullsize.py::test_cfg5_shape_sweep_with_flips.  Accuracy was kept.
 __global__ __launch_bounds__(256) void patch_pivot_cols_kernel(FlipArgs g) {
     const int n = blockIdx.y;
     const int k = g.d_cnt[n];
@@ -820,7 +824,7 @@ int pgl_k_flip_apply(const PglFlipState& s, int have_G, int max_pivots, int wind
     int rc = pgl_launch_gemm(PGL_GEMM_PLAIN, w, st);
     if (rc) return rc;
     // full-tableau form (initial sweep): the update writes the pivot rows and columns itself from patched operand columns
-    static const bool patch_ab = pgl_ab_int("PGL_FLIP_PATCH", 1) != 0;
+    static const bool patch_ab = pgl_ab_int("PGL_FLIP_PATCH", 0) != 0;       // (an experiment of the -DPGL_AB build: see patch_pivot_cols_kernel)
     const bool patch = r0 == 0 && patch_ab;
     if (patch) {
         hipLaunchKernelGGL(patch_pivot_cols_kernel, dim3(64, s.nb), dim3(256), 0, st, g);
