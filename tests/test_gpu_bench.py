@@ -52,3 +52,35 @@ def test_self_launch_two_ranks_equals_one_rank():
     assert rccl["collective"]["backend"] == "nccl" and rccl["collective"]["world"] == 1 and len(rccl["collective"]["devices"]) == 1
     assert rccl["log_likelihood_after"] == one["log_likelihood_after"]
     assert rccl["per_rank"][0]["collectives_ms_per_step"] > 0
+
+
+def test_bench_line_carries_the_box_calibration_and_the_hbm_side_probe():
+    """round 5: `roofline.box_ubench_tops` / `frac_vs_this_box` from pgl_ubench_mfma (register-only MFMA loops, run right before the timed
+    region), `roofline.hbm_side` from the SMU's memory-controller activity (amdsmi), measured in the run; the committed PMC counters are quoted
+    only while their recorded source hash matches the kernel sources (this configuration is not the one they were taken on: null + reason);
+    `per_rank` carries the exposed host share"""
+    d = _bench(1, "--no-fixed-state")
+    r = d["roofline"]
+    assert 2000 < r["box_ubench_tops"] < 5100 and 0 < r["frac_vs_this_box"] < 1 and r["frac"] < r["frac_vs_this_box"]
+    assert 40 < r["box_ubench"]["f64_tflops"] < 79
+    assert r["traffic"] is None and "null" in r["traffic_source"]
+    hb = r["hbm_side"]
+    assert hb is not None
+    if hb.get("available"):                      # (amdsmi reports umc_activity on MI355X; a box without it says why)
+        assert hb["hbm_bytes_per_launch"] > 0 and 70 < hb["calibration"]["gb_per_s_per_pct"] < 95
+    pr = d["per_rank"][0]
+    assert pr["host_busy_ms_per_step"] < pr["ms_per_step"] and pr["launch_call_ms_per_step"] > 0
+
+
+def test_ubench_entry_point():
+    """pgl_ubench_mfma (include/pyglm_hip.h): plausible rates for both instructions, argument checks"""
+    import ctypes
+    from pyglm_amd._lib import call, load, PglError
+    r, ms = ctypes.c_double(), ctypes.c_double()
+    call("pgl_ubench_mfma", 0, 0.2, ctypes.byref(r), ctypes.byref(ms), None)
+    assert 2e15 < r.value < 5.2e15 and ms.value > 0
+    call("pgl_ubench_mfma", 1, 0.2, ctypes.byref(r), None, None)
+    assert 4e13 < r.value < 7.9e13
+    with pytest.raises(PglError):
+        call("pgl_ubench_mfma", 2, 0.2, ctypes.byref(r), None, None)
+    assert b"argument check" in load().pgl_last_error()

@@ -488,3 +488,75 @@ def test_integer_gram_planning_arithmetic():
     assert pays(128, 5, 50000, nloc=2) and pays(128, 5, 50000, nloc=16)   # the choice follows the whole model, not the shard: 1 GPU and 8 take the same path
     assert not pays(2, 320, 50000)           # a model of two neurons does not fill a launch
     assert not pays(32, 5, 50000)            # D = 160: one padded tile against three small fp64 tiles
+
+
+def test_chain_state_lives_in_three_model_arrays_and_the_regressions_see_views():
+    """round 5: a population model keeps (A, W, b) as three arrays; `regressions[n].a / .W / .b` are views of row n (no 3 N copies per sweep,
+    pyglm/models.py:54-64 read-backs unchanged).  The reference's idioms keep working: in-place edits through a regression reach the model,
+    assignment copies values into the row, a regression swapped in from outside is adopted, get_state / set_state restore the link."""
+    from pyglm_amd.models import SparseBernoulliGLM
+    from pyglm_amd.regression import SparseBernoulliRegression
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(6)
+    N, B, T = 5, 2, 200
+    m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=2.0, mu_b=-1.0), seed=3, engine_factory=OracleEngine)
+    A, W, b = m._adopt_state()
+    r2 = m.regressions[2]
+    assert r2.a.base is A and r2.W.base is W and r2.b.shape == (1,) and r2.a.dtype == bool and r2.W.shape == (N, B)
+    r2.a[4] = not r2.a[4]                              # in place through the view
+    assert m.adjacency[2, 4] == r2.a[4]
+    r2.W = np.full((N, B), 7.0)                        # assignment copies the values into the model's row
+    r2.b = np.array([0.25])
+    assert np.all(m.weights[2] == 7.0) and m.biases[2] == 0.25 and r2.W.base is W
+    w = m.weights
+    w[:] = 0.0                                         # the read-backs are copies, as np.array([...]) is in the reference
+    assert np.all(m.weights[2] == 7.0)
+    # a stand-alone regression owns its arrays until a model adopts it
+    other = SparseBernoulliRegression(N, B, S_w=2.0, mu_b=-1.0)
+    oa, oW = other.a.copy(), other.W.copy()
+    assert other._store is None
+    m.regressions[1] = other
+    np.testing.assert_array_equal(m.adjacency[1], oa)
+    np.testing.assert_array_equal(m.weights[1], oW)
+    assert other._store is not None and other.a.base is m._adopt_state()[0]
+    # sweeps write through the arrays; a saved state restores both the values and the link
+    m.add_data((np.random.rand(T, N) < 0.2).astype(float))
+    st = m.get_state()
+    before = (m.adjacency, m.weights, m.biases)
+    m.resample_model()
+    assert not np.array_equal(m.weights, before[1])
+    m.set_state(st)
+    for got, want in zip((m.adjacency, m.weights, m.biases), before):
+        np.testing.assert_array_equal(got, want)
+    assert all(r.a.base is m._adopt_state()[0] for r in m.regressions)
+    m.regressions[0].a[:] = True
+    assert m.adjacency[0].all()
+
+
+def test_counter_files_are_tied_to_the_kernel_sources():
+    """committed hardware-counter summaries record the hash of the kernel sources they were taken on (pyglm_amd._lib.source_hash); bench.py
+    quotes them only on a match.  The hash is stable, 16 hex digits, and moves with the sources."""
+    import json
+    import os
+    import shutil
+    import tempfile
+    from pyglm_amd import _lib
+    h = _lib.source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0 and h == _lib.source_hash()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = json.load(open(os.path.join(root, "profiles", "gram_pmc.json")))
+    assert "source_hash" in pmc["int8"], "profiles/gram_pmc.json: re-take with tools/profile_final.sh (records the source hash)"
+    # a copy of the package with one kernel source touched hashes differently
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copytree(os.path.join(root, "pyglm_amd"), os.path.join(tmp, "pyglm_amd"), ignore=shutil.ignore_patterns("lib", "_build", "__pycache__"))
+        shutil.copytree(os.path.join(root, "include"), os.path.join(tmp, "include"))
+        with open(os.path.join(tmp, "pyglm_amd", "csrc", "pgl_chol.hip"), "a") as f:
+            f.write("// touched\n")
+        here, _lib._HERE = _lib._HERE, os.path.join(tmp, "pyglm_amd")
+        try:
+            assert _lib.source_hash() != h
+        finally:
+            _lib._HERE = here
+    finally:
+        shutil.rmtree(tmp)

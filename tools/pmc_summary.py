@@ -69,4 +69,4 @@ def main(dfetch, dwrite, prefix, planes, group, cmd, dhit=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6], cmd="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp64-compare --no-scaling-proxy --no-fixed-state", dhit=sys.argv[6] if len(sys.argv) > 6 else None)
+    main(*sys.argv[1:6], cmd="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp64-compare --no-scaling-proxy --no-fixed-state --no-hbm-probe --no-box-ubench", dhit=sys.argv[6] if len(sys.argv) > 6 else None)
