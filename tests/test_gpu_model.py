@@ -409,3 +409,51 @@ def test_standalone_regression_cache_is_keyed_by_content():
     assert reg._engine_cache[1] is eng
     reg.resample([(X1, 1.0 - y)], seed=3, sweep=2)                           # different spikes, same X
     assert reg._engine_cache[1] is not eng
+
+
+def test_one_engine_takes_changing_input_forms_sweep_after_sweep():
+    """round 5: a shard's chain state and a sweep's inputs travel as ONE block (engine._io_reserve: one pinned upload, cached pgl_sweep_t).
+    The block is re-laid out when the inputs change form -- a dense prior (N x N blocks), then a table prior with labels (what a network push
+    produces), an omega override, recorded log-odds, a prefix run -- and every sweep must equal the same sweep on a fresh engine."""
+    import torch
+    from pyglm_amd.engine import GibbsEngine, BlockPrior, make_draws, prior_terms
+    rng = np.random.default_rng(12)
+    N, B, T = 9, 2, 600
+    Y = (rng.random((T, N)) < 0.15).astype(float)
+    X = rng.random((T, N, B)) * 0.2
+    a0 = rng.random((N, N)) < 0.5
+    W0 = rng.standard_normal((N, N, B)) * 0.1 * a0[:, :, None]
+    b0 = np.full(N, -1.5)
+    rho = np.full((N, N), 0.4)
+    dense = prior_terms(np.tile(np.eye(B) * 2.0, (N, N, 1, 1)), np.zeros((N, N, B)), np.full(N, 2.0), np.full(N, -1.0))
+    Ju, hu, _, _, cu = prior_terms(np.array([np.eye(B) * 2.0, np.eye(B) * 0.5])[None], np.zeros((1, 2, B)), np.ones(1), np.zeros(1))
+    label = np.zeros((N, N), dtype=np.int32)
+    label[np.arange(N), np.arange(N)] = 1
+    table = (BlockPrior(Ju[0], hu[0], cu[0], label), None, dense[2], dense[3], None)
+    om = rng.random((T, N)) * 0.3 + 0.05
+
+    def run(eng, form, sweep, state, **kw):
+        perm, u, z = make_draws(3, sweep, range(N), N, N * B)
+        hyp = dense if form == "dense" else table
+        return eng.sweep(*state, rho, *hyp, perm, u, z, seed=3, sweep=sweep, **kw)
+
+    plan = [("dense", {}), ("table", {}), ("dense", dict(omega_override=[om])), ("table", dict(nrun=4)), ("dense", {}), ("table", {})]
+    eng = GibbsEngine(N, B)
+    eng.add_data(Y, X=X)
+    state = (a0, W0, b0)
+    for s, (form, kw) in enumerate(plan):
+        eng.keep_logodds = s == 4
+        got = run(eng, form, s, state, **kw)
+        fresh = GibbsEngine(N, B)
+        fresh.add_data(Y, X=X)
+        fresh.keep_logodds = eng.keep_logodds
+        want = run(fresh, form, s, state, **kw)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+        if eng.keep_logodds:
+            assert torch.equal(eng.logodds.nan_to_num(), fresh.logodds.nan_to_num())
+        # the engine's device state is what it returned (packed_state reads it for the per-sweep all_gather)
+        np.testing.assert_array_equal(eng.a_dev.cpu().numpy().astype(bool), got[0])
+        np.testing.assert_array_equal(eng.W_dev.cpu().numpy().reshape(N, N, B), got[1])
+        state = (got[0], got[1], got[2])
+        del fresh
