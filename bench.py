@@ -463,7 +463,6 @@ def main():
         eng.collect_timings()
         c0 = model.comm_seconds
         w0, o0, l0 = getattr(eng, "wait_seconds", 0.0), getattr(eng, "overlap_seconds", 0.0), getattr(eng, "launch_seconds", 0.0)
-        oc0, cpu0 = getattr(eng, "overlap_cpu_seconds", 0.0), time.thread_time()
         barrier()
         if watched and watch:
             watch.start()
@@ -476,9 +475,6 @@ def main():
         st = eng.collect_timings()
         eng.profile = False
         timed.launch = getattr(eng, "launch_seconds", 0.0) - l0
-        # CPU time of this rank's main thread over the region, less what it spent on the overlapped draws: independent of how long the GPU
-        # (or, on a shared GPU, the other ranks) kept it waiting -- provided the runtime's waits sleep rather than spin
-        timed.host_cpu = (time.thread_time() - cpu0) - (getattr(eng, "overlap_cpu_seconds", 0.0) - oc0)
         timed.host_busy = (mine - (model.comm_seconds - c0) - (getattr(eng, "wait_seconds", 0.0) - w0) - (getattr(eng, "overlap_seconds", 0.0) - o0)
                            - timed.launch)
         return allmax(mine), mine, st, model.comm_seconds - c0, pw
@@ -487,7 +483,7 @@ def main():
         model.resample_model()
     ubench = box_ubench() if rank == 0 and not args.no_box_ubench else None
     dt, dt_mine, stages, comm_s, power = timed(args.steps, watched=True)
-    host_busy, launch_s, host_cpu = timed.host_busy, timed.launch, timed.host_cpu
+    host_busy, launch_s = timed.host_busy, timed.launch
     stages = {k_: dict(v_, ms=v_["ms"] / args.steps, calls=v_["calls"] / args.steps, work=v_["work"] / args.steps) for k_, v_ in stages.items()}
 
     # per-rank breakdown: wall time, time inside collectives, GPU time of the top-level stages, and what is left (host-only share)
@@ -498,8 +494,7 @@ def main():
             # wall time less the waits for the GPU (pgl_get_state), the waits inside collectives, the host work done while the GPU was busy
             # (the next sweep's random inputs) and the pgl_sweep call itself (its ~3 000 launches overlap the GPU's work; when several ranks share
             # one GPU the call also waits for room in the queue): what the host adds to a sweep on this rank
-            "host_busy_ms_per_step": host_busy / args.steps * 1e3, "launch_call_ms_per_step": launch_s / args.steps * 1e3,
-            "host_cpu_ms_per_step": host_cpu / args.steps * 1e3}
+            "host_busy_ms_per_step": host_busy / args.steps * 1e3, "launch_call_ms_per_step": launch_s / args.steps * 1e3}
     per_rank = [mine]
     if use_dist:
         per_rank = [None] * world

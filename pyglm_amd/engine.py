@@ -167,7 +167,6 @@ class GibbsEngine(object):
         # busy (host_overlap) -- what a rank's wall time has to be cleared of to see its exposed host share (bench.py: host_busy_ms_per_step)
         self.wait_seconds = 0.0
         self.overlap_seconds = 0.0
-        self.overlap_cpu_seconds = 0.0 # CPU time of the calling thread inside host_overlap
         self.launch_seconds = 0.0      # inside the pgl_sweep call itself: ~3 000 launches at the headline size (and, when the queue is full, waiting)
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
@@ -711,10 +710,9 @@ class GibbsEngine(object):
         if after_queue is not None:
             after_queue(self)
         if host_overlap is not None:
-            t_ov, c_ov = time.perf_counter(), time.thread_time()
+            t_ov = time.perf_counter()
             host_overlap()
             self.overlap_seconds += time.perf_counter() - t_ov
-            self.overlap_cpu_seconds += time.thread_time() - c_ov
         t_wait = time.perf_counter()
         # state, log-likelihood and flags back into the pinned twin of the state block (pgl_get_state waits for the stream)
         hout = self._hout_np
