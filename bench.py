@@ -537,6 +537,10 @@ def main():
     scaling = None
     if world == 1 and not args.no_scaling_proxy and not model._shard_override and cfg.get("obs") is None and N % 8 == 0 and N >= 64:
         scaling = scaling_proxy(model, eng, N, B, T)
+        if fixed:
+            # the proxy sweeps start from the chain state fixed_state was measured at (sweep warmup + steps), which is sparser than the states
+            # `value` averages over: compare a rank's time with THIS one-GPU time, not with ms_per_step
+            scaling["one_gpu_sweep_ms_same_state"] = fixed["ms_per_step"]
 
     # ---- the two Gram paths from the same state (consistency), then the fp64 path timed on its own
     cmp64 = consistency = None
