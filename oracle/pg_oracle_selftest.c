@@ -26,7 +26,7 @@ int main(void) {
         for (int i = 0; i < 4; ++i) if (o[i] != want1[i]) { fprintf(stderr, "philox KAT 1 word %d: %08x != %08x\n", i, o[i], want1[i]); return 1; }
     }
     const size_t n = 20000;
-    const double shapes[] = {1.0, 2.0, 0.3, 2.5, 7.0, 13.7, 50.0, 70.5};
+    const double shapes[] = {1.0, 2.0, 0.3, 1.02, 1.5, 2.5, 7.0, 13.7, 50.0, 63.99, 70.5};      /* incl. the alternate sampler (fractional part of 1 < b < 64) */
     const double zs[] = {0.0, 0.7, 3.0, 12.0};
     double* b = (double*)malloc(n * sizeof(double));
     double* z = (double*)malloc(n * sizeof(double));
