@@ -472,10 +472,20 @@ __device__ __forceinline__ void big_mfma(v4i& acc, const v4i& a, const v4i& b) {
 
 // TRI: the wave tile straddles the diagonal (a diagonal wave of a diagonal tile): the 16 x 16 blocks strictly above it (J > I) are
 // never read, so their MFMAs are not issued (45 of 100); the slots keep their places
+// ORDER OF ISSUE.  Step J of row I multiplies FA[I] by FB[JJ].  Row-major (JJ = J) changes the B operand on every instruction and BOTH operands
+// at every row change; under the package power limit the multipliers' input switching is energy, i.e. time.  Odd rows (but the last) therefore
+// run their columns backwards: the B fragment of a row's last MFMA is the first of the next row, and only the A operand changes there.  Rows 0
+// and 9 keep the forward order, because the B fragments of the next K tile are reloaded behind row 9's MFMAs in the order row 0 wants them.
+// (tools/ubench_i8_order.hip, register-only 8 x 4 blocks on random bytes: row-major 3.98 POP/s, boustrophedon 4.07, both operands changing
+// on every instruction 3.84.)  Same products, same exact integer sums.
+#ifndef PGL_I8_SNAKE
+#define PGL_I8_SNAKE 1
+#endif
 template <bool TRI, int I, int J, typename F>
 __device__ __forceinline__ void big_rows(v4i (&acc)[10][10], v4i (&FA)[5], v4i (&FB)[10], F&& slot) {
     if constexpr (I < 10) {
-        if constexpr (!TRI || J <= I) big_mfma<I * 10 + J>(acc[I][J], FA[I % 5], FB[J]);
+        constexpr int JJ = (PGL_I8_SNAKE && (I & 1) && I != 9) ? 9 - J : J;
+        if constexpr (!TRI || JJ <= I) big_mfma<I * 10 + JJ>(acc[I][JJ], FA[I % 5], FB[JJ]);
         slot(std::integral_constant<int, I>{}, std::integral_constant<int, J>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (J == 9) big_rows<TRI, I + 1, 0>(acc, FA, FB, slot);
