@@ -168,10 +168,16 @@ class PowerWatch(object):
         self._thread.start()
         return self
 
-    def stop(self):
+    def stop(self, skip_seconds=0.0):
+        """ends the sampling thread (joined BEFORE the samples are touched) and summarises; skip_seconds drops the samples of the region's first
+        seconds (the SMU averages over a window)"""
         self._stop = True
         if self._thread is not None:
             self._thread.join()
+            self._thread = None
+        if skip_seconds > 0 and self.samples:
+            t_first = self.samples[0][0]
+            self.samples = [x for x in self.samples if x[0] - t_first >= skip_seconds] or self.samples
         if not self.samples:
             return {"available": False, "error": self.err}
         w = np.array([x[1] for x in self.samples])
@@ -233,9 +239,7 @@ def hbm_side_probe(eng, watch, seconds=3.0):
             n += 2
         e1.record()
         torch.cuda.synchronize()
-        t_first = watch.samples[0][0] if watch.samples else 0.0
-        watch.samples = [x for x in watch.samples if x[0] - t_first >= 1.0] or watch.samples
-        rec = watch.stop()
+        rec = watch.stop(skip_seconds=1.0)
         watch.period = 0.2
         return e0.elapsed_time(e1) / n, rec
     try:
@@ -258,37 +262,89 @@ def hbm_side_probe(eng, watch, seconds=3.0):
         return {"available": False, "error": repr(e)}
 
 
-def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8), sweeps=2):
-    """One rank's share of a G-GPU run of the same model, on this GPU: rank 0 of G owns neurons [0, N/G) (models.py:169-171 sharded by
-    postsynaptic neuron, shard_bounds); its sweep is pgl_sweep over those neurons (engine.sweep(nrun=N/G): same kernels, same batches as
-    a real rank would use at this batch size), then the all_gather of (a, W, b) rows and the network prior, which every rank repeats on
-    the host.  The first two are timed here; the all_gather cannot be (one GPU) and is given as its payload.  NOT measured scaling."""
+def gather_cost_one_rank(model, eng, reps=3):
+    """what the per-sweep exchange costs a rank apart from the wire: pack on the device -> all_gather_into_tensor over RCCL -> read-back of all N
+    rows -> unpack, timed with the ONE rank a one-GPU box gives RCCL (a temporary 1-rank "nccl" group unless the run already has one).  With G
+    ranks every rank still reads back and unpacks all N rows; what one rank cannot show is the transfer itself, bounded in `wire_note`."""
     import torch
+    import torch.distributed as dist
+    made = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=eng.dev)
+            made = True
+        if dist.get_backend() != "nccl" or dist.get_world_size() != 1:
+            return {"available": False, "error": "needs a one-rank nccl group"}
+        ms = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.device(eng.dev):
+                h = model._gather_start(eng.packed_state())
+            rows = model._gather_finish(h)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        assert rows[1].shape == (model.N, model.N, model.B)
+        pay = int(h[1].numel())
+        return {"available": True, "ms": float(np.median(ms[1:])), "ms_all": [round(x, 3) for x in ms], "payload_bytes": pay, "backend": "nccl", "world": 1,
+                "what": "packed_state (device) + all_gather_into_tensor + device->host copy of all N rows + unpack, median of %d after one warm-up" % reps,
+                "wire_note": "not in `ms`: moving (G-1)/G of the payload between GPUs -- %.2f ms if it all went over ONE xGMI link at 153 GB/s, less on the "
+                             "node's point-to-point links used side by side" % (pay / 153e9 * 1e3)}
+    except Exception as e:          # noqa: BLE001
+        return {"available": False, "error": repr(e)}
+    finally:
+        if made:
+            dist.destroy_process_group()
+
+
+def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8)):
+    """What a G-GPU run of the same model would take, from THIS GPU: the neurons shard by postsynaptic neuron (models.py:169-171,
+    shard_bounds); EVERY one of the G shards is swept here on its own (engine.sweep(nrun, nfirst): pgl_sweep over neurons [lo, hi), batched as
+    the owning rank would batch them, from the bench chain's current state, which is not advanced), because a sweep ends when the SLOWEST
+    rank does -- flip and weight time follow each row's active-set size.  Then the replicated host-side network prior (timed) and the
+    per-sweep gather as far as one rank can time it (gather_cost_one_rank).  projected = 1 / (max over shards + network + gather).
+    NOT measured scaling: no second GPU was involved."""
+    import torch
+    from pyglm_amd.models import shard_bounds
     inputs = model._sweep_inputs()
     state = model.get_state()
     t0 = time.perf_counter()
     model.resample_network()
     t_net = time.perf_counter() - t0
     model.set_state(state)
+    del state
+    gather = gather_cost_one_rank(model, eng)
+    t_gather = gather["ms"] * 1e-3 if gather.get("available") else 0.0
     rows = []
     for G in groups:
-        k = N // G
-        eng.profile = True
-        eng.collect_timings()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(sweeps):
-            eng.sweep(*inputs, model.seed, model.sweeps_done, nrun=k)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / sweeps
-        st = eng.collect_timings()
-        eng.profile = False
-        rows.append({"gpus": G, "neurons_per_rank": k, "batches": -(-k // eng.nb), "rank_sweep_ms": dt * 1e3,
-                     "rank_sweep_plus_network_ms": (dt + t_net) * 1e3, "projected_sweeps_per_s": 1.0 / (dt + t_net),
-                     "stages_ms": {n: round(v["ms"] / sweeps, 1) for n, v in st.items() if n in TOP_STAGES}})
-    return {"note": "one-rank proxy, not measured scaling: the sweep of the first N/G neurons from the bench chain's current state on THIS GPU "
-                    "(%d sweeps each), plus the replicated host-side network prior; the per-sweep all_gather of the (a, W, b) rows is not included" % sweeps,
-            "host_network_prior_ms": t_net * 1e3, "allgather_payload_bytes": int(N * N + 8 * N * N * B + 8 * N),
+        shard_ms, tables = [], []
+        for r in range(G):
+            lo, hi = shard_bounds(N, G, r)
+            eng.profile = TOP_STAGES
+            eng.collect_timings()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.sweep(*inputs, model.seed, model.sweeps_done, nrun=hi - lo, nfirst=lo)
+            torch.cuda.synchronize()
+            shard_ms.append((time.perf_counter() - t0) * 1e3)
+            st = eng.collect_timings()
+            eng.profile = False
+            tables.append({n: round(v["ms"], 1) for n, v in st.items() if n in TOP_STAGES})
+        worst, best = int(np.argmax(shard_ms)), int(np.argmin(shard_ms))
+        mx, mean = max(shard_ms), float(np.mean(shard_ms))
+        rows.append({"gpus": G, "neurons_per_rank": N // G, "batches_per_rank": -(-(N // G) // eng.nb),
+                     "shard_sweep_ms": [round(x, 1) for x in shard_ms], "max_ms": mx, "mean_ms": mean, "imbalance_max_over_mean": mx / mean,
+                     "sum_ms": float(np.sum(shard_ms)),
+                     "rank_sweep_plus_network_plus_gather_ms": mx + (t_net + t_gather) * 1e3,
+                     "projected_sweeps_per_s": 1.0 / (mx * 1e-3 + t_net + t_gather),
+                     "slowest_shard": {"rank": worst, "stages_ms": tables[worst]}, "fastest_shard": {"rank": best, "stages_ms": tables[best]}})
+    return {"note": "projection, not measured scaling: every shard of a G-rank job swept on THIS GPU from the bench chain's current state (one sweep "
+                    "each; the chain is not advanced); projected = 1 / (slowest shard + replicated host-side network prior + the per-sweep gather as one "
+                    "rank can time it)",
+            "host_network_prior_ms": t_net * 1e3, "gather": gather, "allgather_payload_bytes": int(N * (8 * N * B + 16 + -(-N // 8) * 8)),
             "per_gpu_count": rows}
 
 

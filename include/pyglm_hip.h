@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PGL_ABI_VERSION 10
+#define PGL_ABI_VERSION 11
 
 int pgl_abi_version(void);
 const char* pgl_last_error(void);
@@ -282,8 +282,10 @@ typedef struct {
                                     * read once per batch instead of once per group of 8 neurons.  The scales can only come out SMALLER than
                                     * from the exact column statistics (a column that one element dominates loses a bit or two of its 50);
                                     * NULL: pgl_i8_colstats per group */
-    int nrun;                      /* sweep only the first nrun local neurons (0 = all nloc): what a rank of a larger job would do, timed on
-                                    * this GPU (bench.py scaling_proxy); the state of the others is left alone */
+    int nrun;                      /* sweep only nrun local neurons (0 = all nloc), those from nfirst on: what a rank of a larger job would do,
+                                    * timed on this GPU (bench.py scaling_proxy); the state of the others is left alone */
+    int nfirst;                    /* first local neuron of such a partial sweep (even; 0 with nrun = 0): the shard [nfirst, nfirst + nrun) of a
+                                    * G-rank job is batched from nfirst on, as the rank that owns it would batch it */
     /* hints (0 = unknown): nothing depends on them but the number of (possibly empty) launches -- in particular not a bit of the result, so
      * that a shard reproduces its rows of the whole model */
     int all_deterministic;         /* 1: the caller knows every row has rho in {0, 1} (regression.py:153-155): the flip stage is not launched */

@@ -133,16 +133,16 @@ static double pg_rtigauss(double Z, pg_rng* r) {
     Z = fabs(Z);
     if (1.0 / t > Z) { /* mu > t: rejection from the Levy-type proposal */
         double alpha = 0.0;
-        while (rng_unif(r) > alpha) {
+        for (int i = 0; i < 10000 && rng_unif(r) > alpha; ++i) {
             double E1 = rng_expon(r), E2 = rng_expon(r);
-            while (E1 * E1 > 2 * E2 / t) { E1 = rng_expon(r); E2 = rng_expon(r); }
+            for (int q = 0; q < 10000 && E1 * E1 > 2 * E2 / t; ++q) { E1 = rng_expon(r); E2 = rng_expon(r); }
             X = 1 + E1 * t;
             X = t / (X * X);
             alpha = exp(-0.5 * Z * Z * X);
         }
     } else { /* mu <= t: Michael-Schucany-Haas, retried until X <= t */
         const double mu = 1.0 / Z;
-        while (X > t) {
+        for (int i = 0; i < 10000 && X > t; ++i) {
             double Y = rng_norm(r);
             Y *= Y;
             const double half_mu = 0.5 * mu, mu_Y = mu * Y;
@@ -156,19 +156,18 @@ static double pg_rtigauss(double Z, pg_rng* r) {
 static double pg_draw_one(double z, pg_rng* r) {
     const double Z = fabs(z) * 0.5;
     const double fz = 0.125 * PG_PI * PG_PI + 0.5 * Z * Z;
-    for (;;) {
+    for (int trial = 0; trial < 10000; ++trial) {
         double X;
         if (rng_unif(r) < pg_mass_texpon(Z)) X = PG_TRUNC + rng_expon(r) / fz;
         else X = pg_rtigauss(Z, r);
         double S = pg_a(0, X);
         const double Y = rng_unif(r) * S;
-        int n = 0;
-        for (;;) {
-            ++n;
+        for (int n = 1; n < 1000; ++n) {
             if (n & 1) { S -= pg_a(n, X); if (Y <= S) return 0.25 * X; }
             else       { S += pg_a(n, X); if (Y > S) break; }
         }
     }
+    return NAN;
 }
 
 /* ------------------------------------------------------------------ PG(h, z) for 1 < h < 2: Windle's "alternate" sampler
@@ -229,38 +228,48 @@ static double gamma_q(double a, double x) {
 }
 
 /* Gamma(shape, rate) restricted to (trunc, inf), shape > 1: Dagpunar's (1978) shifted-exponential rejection */
+/* 1 - c0 is formed without the subtraction: as shape -> 1 the optimal rate c0 -> 1 and 1 - c0 = 2 (a - 1) / (b + a + root) would otherwise
+ * round to 0 (log M = +inf: nothing is ever accepted).  Loops are bounded (PG_MAX_TRIALS, BayesLogit's bound); exhaustion gives NaN. */
+#define PG_MAX_TRIALS 10000
+#define PG_MAX_INNER 1000
+#define PG_FRAC_EPS 1e-9
 static double rng_ltgamma(double shape, double rate, double trunc, pg_rng* r) {
     const double a = shape, b = rate * trunc, d1 = b - a, d3 = a - 1.0;
-    const double c0 = 0.5 * (d1 + sqrt(d1 * d1 + 4.0 * b)) / b;
-    const double lM = d3 * log(d3 / (1.0 - c0)) - d3;
-    for (;;) {
+    const double root = sqrt(d1 * d1 + 4.0 * b);
+    const double c0 = 0.5 * (d1 + root) / b;
+    const double one_m_c0 = 2.0 * d3 / (b + a + root);
+    const double lM = d3 * log(0.5 * (b + a + root)) - d3;
+    for (int i = 0; i < PG_MAX_TRIALS; ++i) {
         const double x = b + rng_expon(r) / c0;
         const double u = rng_unif(r);
-        if (log(u) <= d3 * log(x) - x * (1.0 - c0) - lM) return trunc * (x / b);
+        if (log(u) <= d3 * log(x) - x * one_m_c0 - lM) return trunc * (x / b);
     }
+    return NAN;
 }
 
 /* inverse Gaussian(mu = h / z, lambda = h^2) restricted to (0, t] */
 static double pg_alt_left(double h, double z, double t, pg_rng* r) {
     if (z * t < h) {            /* mu > t: x = h^2 / G^2 with G a standard normal beyond h / sqrt(t) (Robert 1995), thinned by exp(-z^2 x / 2) */
         const double c = h / sqrt(t), ar = 0.5 * (c + sqrt(c * c + 4.0));
-        for (;;) {
-            double G;
-            for (;;) {
+        for (int i = 0; i < PG_MAX_TRIALS; ++i) {
+            double G = 0.0;
+            for (int q = 0; q < PG_MAX_TRIALS; ++q) {
                 G = c + rng_expon(r) / ar;
                 if (rng_unif(r) <= exp(-0.5 * (G - ar) * (G - ar))) break;
             }
             const double X = h * h / (G * G);
             if (rng_unif(r) <= exp(-0.5 * z * z * X)) return X;
         }
+        return NAN;
     }
     const double mu = h / z, lam = h * h;
-    for (;;) {                  /* Michael, Schucany & Haas (1976), retried until x <= t */
+    for (int i = 0; i < PG_MAX_TRIALS; ++i) {                  /* Michael, Schucany & Haas (1976), retried until x <= t */
         const double N = rng_norm(r), Y = N * N;
         double X = mu + 0.5 * mu * mu * Y / lam - 0.5 * mu / lam * sqrt(4.0 * mu * lam * Y + mu * mu * Y * Y);
         if (rng_unif(r) > mu / (mu + X)) X = mu * mu / X;
         if (X <= t) return X;
     }
+    return NAN;
 }
 
 static double pg_alt_a(int n, double x, double h, double coef, double* cn) {      /* a_n(x | h); *cn carries Gamma(n + h) / (Gamma(n + 1) Gamma(h)) */
@@ -282,12 +291,13 @@ static double pg_alt(double h, double zpg, pg_rng* r) {       /* one draw of PG(
     const double pr = wr / (wl + wr);
     const double coef = exp(hl2 - 0.5 * log(2.0 * PG_PI));
     const double lgh = lgamma(h);
-    for (;;) {
+    for (int trial = 0; trial < PG_MAX_TRIALS; ++trial) {
         const double X = rng_unif(r) < pr ? rng_ltgamma(h, lam, t, r) : pg_alt_left(h, z, t, r);
+        if (!(X > 0.0)) break;
         double cn, S = pg_alt_a(0, X, h, coef, &cn), prev = S;
         const double env = X > t ? exp(h * log(0.5 * PG_PI) + (h - 1.0) * log(X) - 0.125 * PG_PI * PG_PI * X - lgh) : S;
         const double Y = rng_unif(r) * env;
-        for (int n = 1;; ++n) {
+        for (int n = 1; n < PG_MAX_INNER; ++n) {
             const double an = pg_alt_a(n, X, h, coef, &cn);
             const int dec = an <= prev;
             prev = an;
@@ -295,6 +305,7 @@ static double pg_alt(double h, double zpg, pg_rng* r) {       /* one draw of PG(
             else       { S += an; if (Y > S && dec) break; }
         }
     }
+    return NAN;
 }
 
 /* ------------------------------------------------------------------ PG(b, z) for real b > 0
@@ -315,12 +326,13 @@ static double rng_gamma(double alpha, pg_rng* r) {
     double boost = 1.0;
     if (alpha < 1.0) { boost = exp(log(rng_unif(r)) / alpha); alpha += 1.0; }
     const double d = alpha - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-    for (;;) {
+    for (int trial = 0; trial < 10000; ++trial) {
         double x, v;
         do { x = rng_norm(r); v = 1.0 + c * x; } while (v <= 0.0);
         v = v * v * v;
         if (log(rng_unif(r)) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
     }
+    return NAN;
 }
 
 static void pg_tail_sums(double c, double* S1, double* S2) {
@@ -367,9 +379,12 @@ int oracle_pg_draw(const double* b, const double* z, double* out, size_t len,
         r.s_lo = (uint32_t)stream; r.s_hi = (uint32_t)(stream >> 32);
         r.j = 0; r.purpose = PG_PURPOSE_PG; r.have = 0;
         double s = 0.0;
-        if (bi > (double)PG_DEVROYE_MAX) s = pg_series(bi, z[i], &r);
+        if (bi > 0.0 && !isfinite(z[i])) s = NAN;             /* psi = nan / +-inf: no draw (and no loop to spin in) */
+        else if (bi > (double)PG_DEVROYE_MAX) s = pg_series(bi, z[i], &r);
         else if (bi > 0.0) {
-            const double fl = floor(bi), frac = bi - fl;
+            double fl = floor(bi), frac = bi - fl;
+            if (fl >= 1.0 && frac < PG_FRAC_EPS) frac = 0.0;   /* shapes within 1e-9 of an integer (y + xi with xi = 1.1 * 1.1 / 1.21) are that integer */
+            else if (fl >= 1.0 && frac > 1.0 - PG_FRAC_EPS) { frac = 0.0; fl += 1.0; }
             if (fl < 1.0) s = pg_series(frac, z[i], &r);
             else {
                 const int whole = frac > 0.0 ? (int)fl - 1 : (int)fl;

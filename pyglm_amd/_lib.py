@@ -42,7 +42,7 @@ class Sweep(ctypes.Structure):       # pgl_sweep_t
                 ("Wt", c_p), ("bias", c_p), ("border", c_p), ("skip", c_p), ("c0_dense", c_p),
                 ("Jbuf", c_p), ("Mtab", c_p), ("Ac", c_p), ("hc", c_p), ("Tinv", c_p), ("G", c_p), ("Lws", c_p), ("Ut", c_p), ("Wt_ws", c_p),
                 ("d_idx", c_p), ("d_sign", c_p), ("d_cnt", c_p), ("batch_k", c_p), ("act", c_p), ("na", c_p),
-                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p), ("i8_slice", c_i), ("i8_PAs", c_p), ("i8_Rx", c_p), ("i8_norm", c_p), ("nrun", c_i),
+                ("i8_PB", c_p), ("i8_R", c_p), ("i8_stat", c_p), ("i8_slice", c_i), ("i8_PAs", c_p), ("i8_Rx", c_p), ("i8_norm", c_p), ("nrun", c_i), ("nfirst", c_i),
                 ("all_deterministic", c_i), ("init_rows_bound", c_i), ("active_rows_bound", c_i), ("flip_single_pass", c_i),
                 ("times", ctypes.POINTER(StageTimes))]
 
@@ -95,7 +95,7 @@ SIGNATURES = {
     "pgl_ubench_mfma": [c_i, c_d, ctypes.POINTER(c_d), ctypes.POINTER(c_d), c_p],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

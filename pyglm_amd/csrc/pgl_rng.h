@@ -19,6 +19,9 @@
 
 #define PGL_PURPOSE_PG 1u
 #define PGL_PG_TRUNC 0.64
+#define PGL_PG_MAX_TRIALS 10000     // bound of every rejection loop (BayesLogit's own bound); never met on finite input
+#define PGL_PG_MAX_INNER 1000       // bound of the alternating partial sums (they decide within a few terms)
+#define PGL_PG_FRAC_EPS 1e-9        // a shape within 1e-9 of an integer is that integer (y + xi with xi = 1.1 * 1.1 / 1.21)
 #define PGL_PI 3.141592653589793238462643383279502884
 
 struct PglPhilox {
@@ -96,16 +99,16 @@ __device__ __forceinline__ double pgl_pg_rtigauss(double Z, PglPhilox& r) {
     Z = fabs(Z);
     if (1.0 / t > Z) {
         double alpha = 0.0;
-        while (pgl_unif(r) > alpha) {
+        for (int i = 0; i < PGL_PG_MAX_TRIALS && pgl_unif(r) > alpha; ++i) {
             double E1 = pgl_expon(r), E2 = pgl_expon(r);
-            while (E1 * E1 > 2 * E2 / t) { E1 = pgl_expon(r); E2 = pgl_expon(r); }
+            for (int q = 0; q < PGL_PG_MAX_TRIALS && E1 * E1 > 2 * E2 / t; ++q) { E1 = pgl_expon(r); E2 = pgl_expon(r); }
             X = 1 + E1 * t;
             X = t / (X * X);
             alpha = exp(-0.5 * Z * Z * X);
         }
     } else {
         const double mu = 1.0 / Z;
-        while (X > t) {
+        for (int i = 0; i < PGL_PG_MAX_TRIALS && X > t; ++i) {
             double Y = pgl_norm(r);
             Y *= Y;
             const double half_mu = 0.5 * mu, mu_Y = mu * Y;
@@ -120,19 +123,18 @@ __device__ __forceinline__ double pgl_pg1(double z, PglPhilox& r) {
     const double Z = fabs(z) * 0.5;
     const double fz = 0.125 * PGL_PI * PGL_PI + 0.5 * Z * Z;
     const double mass = pgl_pg_mass_texpon(Z);
-    for (;;) {
+    for (int trial = 0; trial < PGL_PG_MAX_TRIALS; ++trial) {
         double X;
         if (pgl_unif(r) < mass) X = PGL_PG_TRUNC + pgl_expon(r) / fz;
         else X = pgl_pg_rtigauss(Z, r);
         double S = pgl_pg_a(0, X);
         const double Y = pgl_unif(r) * S;
-        int n = 0;
-        for (;;) {
-            ++n;
+        for (int n = 1; n < PGL_PG_MAX_INNER; ++n) {
             if (n & 1) { S -= pgl_pg_a(n, X); if (Y <= S) return 0.25 * X; }
             else       { S += pgl_pg_a(n, X); if (Y > S) break; }
         }
     }
+    return __longlong_as_double(0x7ff8000000000000LL);
 }
 
 // Gamma(alpha, 1), alpha > 0: Marsaglia & Tsang (2000), without the squeeze step; alpha < 1 through Gamma(alpha + 1) U^(1/alpha)
@@ -140,12 +142,13 @@ __device__ __forceinline__ double pgl_gamma(double alpha, PglPhilox& r) {
     double boost = 1.0;
     if (alpha < 1.0) { boost = exp(log(pgl_unif(r)) / alpha); alpha += 1.0; }
     const double d = alpha - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-    for (;;) {
+    for (int trial = 0; trial < PGL_PG_MAX_TRIALS; ++trial) {
         double x, v;
-        do { x = pgl_norm(r); v = 1.0 + c * x; } while (v <= 0.0);
+        do { x = pgl_norm(r); v = 1.0 + c * x; } while (v <= 0.0);      // P(v <= 0) < 1e-3 per pass
         v = v * v * v;
         if (log(pgl_unif(r)) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
     }
+    return __longlong_as_double(0x7ff8000000000000LL);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -205,39 +208,44 @@ __device__ __forceinline__ double pgl_pg_alt(double h, double zpg, PglPhilox& r)
     const double p_right = m_right / (m_left + m_right);
     const double coef = exp(h2 - 0.5 * log(2.0 * PGL_PI)), lgh = lgamma(h);
     // constants of the two proposal samplers
-    const double gb = rate * t, gd = gb - h, ge = h - 1.0, gc = 0.5 * (gd + sqrt(gd * gd + 4.0 * gb)) / gb;   // truncated gamma (Dagpunar 1978)
-    const double glm = ge * log(ge / (1.0 - gc)) - ge;
+    const double gb = rate * t, gd = gb - h, ge = h - 1.0, gs = sqrt(gd * gd + 4.0 * gb), gc = 0.5 * (gd + gs) / gb;   // truncated gamma (Dagpunar 1978)
+    const double g1c = 2.0 * ge / (gb + h + gs);                                   // 1 - gc without the cancellation (gc -> 1 as h -> 1)
+    const double glm = ge * log(0.5 * (gb + h + gs)) - ge;                         // = ge log(ge / (1 - gc)) - ge
     const bool tail = z * t < h;                                                   // inverse-Gaussian mean h / z beyond t
     const double nc = h / rt, na = 0.5 * (nc + sqrt(nc * nc + 4.0));               // normal tail beyond nc (Robert 1995)
     const double mu = tail ? 0.0 : h / z, lam = h * h;
-    for (;;) {
-        double X;
+    // every loop is bounded (PGL_PG_MAX_TRIALS; the acceptance rates are > 0.3, so a bound of 10 000 is never met on finite input):
+    // an exhausted loop returns NaN, which the posterior system's status word reports -- a lane must never spin
+    for (int trial = 0; trial < PGL_PG_MAX_TRIALS; ++trial) {
+        double X = -1.0;
         if (pgl_unif(r) < p_right) {
-            for (;;) {
+            for (int i = 0; i < PGL_PG_MAX_TRIALS; ++i) {
                 const double x = gb + pgl_expon(r) / gc;
                 const double u = pgl_unif(r);
-                if (log(u) <= ge * log(x) - x * (1.0 - gc) - glm) { X = t * (x / gb); break; }
+                if (log(u) <= ge * log(x) - x * g1c - glm) { X = t * (x / gb); break; }
             }
         } else if (tail) {
-            for (;;) {
-                double G;
-                do { G = nc + pgl_expon(r) / na; } while (pgl_unif(r) > exp(-0.5 * (G - na) * (G - na)));
-                X = lam / (G * G);
-                if (pgl_unif(r) <= exp(-0.5 * z * z * X)) break;
+            for (int i = 0; i < PGL_PG_MAX_TRIALS; ++i) {
+                double G = 0.0;
+                for (int q = 0; q < PGL_PG_MAX_TRIALS; ++q) { G = nc + pgl_expon(r) / na; if (pgl_unif(r) <= exp(-0.5 * (G - na) * (G - na))) break; }
+                const double Xc = lam / (G * G);
+                if (pgl_unif(r) <= exp(-0.5 * z * z * Xc)) { X = Xc; break; }
             }
         } else {
-            do {
+            for (int i = 0; i < PGL_PG_MAX_TRIALS; ++i) {
                 const double N = pgl_norm(r), Y = N * N;
-                X = mu + 0.5 * mu * mu * Y / lam - 0.5 * mu / lam * sqrt(4.0 * mu * lam * Y + mu * mu * Y * Y);
-                if (pgl_unif(r) > mu / (mu + X)) X = mu * mu / X;
-            } while (X > t);
+                double Xc = mu + 0.5 * mu * mu * Y / lam - 0.5 * mu / lam * sqrt(4.0 * mu * lam * Y + mu * mu * Y * Y);
+                if (pgl_unif(r) > mu / (mu + Xc)) Xc = mu * mu / Xc;
+                if (Xc <= t) { X = Xc; break; }
+            }
         }
+        if (!(X > 0.0)) break;
         const double lx = 1.5 * log(X), ix = 0.5 / X;
         double cn = 1.0;                                                           // Gamma(n + h) / (Gamma(n + 1) Gamma(h))
         double S = coef * exp(log(h) - lx - h * h * ix), prev = S;
         const double env = X > t ? exp(h * log(0.5 * PGL_PI) + ge * log(X) - 0.125 * PGL_PI * PGL_PI * X - lgh) : S;
         const double Y = pgl_unif(r) * env;
-        for (int n = 1;; ++n) {
+        for (int n = 1; n < PGL_PG_MAX_INNER; ++n) {
             cn *= (n + ge) / n;
             const double d = 2.0 * n + h;
             const double an = coef * cn * exp(log(d) - lx - d * d * ix);
@@ -247,6 +255,7 @@ __device__ __forceinline__ double pgl_pg_alt(double h, double zpg, PglPhilox& r)
             else { S += an; if (Y > S && dec) break; }
         }
     }
+    return __longlong_as_double(0x7ff8000000000000LL);
 }
 
 #define PGL_PG_SERIES_TERMS 32
@@ -279,9 +288,12 @@ __device__ __forceinline__ double pgl_pg_draw(double b, double z, uint64_t seed,
     PglPhilox r;
     pgl_rng_init(r, seed, stream, elem, PGL_PURPOSE_PG);
     if (!(b > 0.0)) return 0.0;
+    if (!(fabs(z) <= 1.7976931348623157e308)) return __longlong_as_double(0x7ff8000000000000LL);   // psi = nan / +-inf: no draw, and no loop to spin in
     if (b > (double)PGL_PG_DEVROYE_MAX) return pgl_pg_series(b, z, r);
-    const double fl = floor(b), frac = b - fl;
+    double fl = floor(b), frac = b - fl;
     if (fl < 1.0) return pgl_pg_series(frac, z, r);
+    if (frac < PGL_PG_FRAC_EPS) frac = 0.0;                                 // rounding-level fractional parts: the integer shape
+    else if (frac > 1.0 - PGL_PG_FRAC_EPS) { frac = 0.0; fl += 1.0; }
     // exact for every 1 <= b <= 64: whole Devroye draws, and the fractional part as ONE draw of PG(1 + frac, z) from the alternate sampler
     const int whole = frac > 0.0 ? (int)fl - 1 : (int)fl;
     double s = 0.0;

@@ -139,9 +139,11 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     PGL_CHECK_ARG(s->Wt && s->bias && s->border && s->skip && s->Jbuf && s->Mtab && s->Ac && s->hc && s->Tinv && s->G && s->Lws && s->Ut && s->Wt_ws);
     PGL_CHECK_ARG(s->d_idx && s->d_sign && s->d_cnt && s->batch_k && s->act && s->na && (s->label == nullptr || s->c0_dense != nullptr));
     PGL_CHECK_ARG(s->obs != 2 || (s->inv_eta && s->G0));
-    PGL_CHECK_ARG(s->nrun >= 0 && s->nrun <= s->nloc && s->i8_slice >= 0 && s->i8_slice % 64 == 0);
+    PGL_CHECK_ARG(s->nrun >= 0 && s->nfirst >= 0 && s->nfirst % 2 == 0 && s->nfirst + s->nrun <= s->nloc && (s->nrun > 0 || s->nfirst == 0));
+    PGL_CHECK_ARG(s->i8_slice >= 0 && s->i8_slice % 64 == 0);
     const int N = s->N, B = s->B, nloc = s->nloc;
-    const int nrun = s->nrun > 0 ? s->nrun : nloc;        // neurons actually swept (a prefix of the shard; the array layouts stay the shard's)
+    const int nrun = s->nrun > 0 ? s->nrun : nloc;        // neurons actually swept: [nf, nf + nrun) of the shard (the array layouts stay the shard's)
+    const int nf = s->nfirst;
     const int nb = s->nb < nrun ? s->nb : nrun;
     const long D = (long)N * B;
     const int Dp = r_up(D + 1, 16), ldn = r_up(nloc, 2), ldj = r_up(D + 2, 16);
@@ -170,12 +172,13 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
         auto m = clk.tic(ST_ACT, 2.0 * d.T * D * nrun);
-        RC(pgl_activation(d.Xt, d.Tp, s->Wt, ldn, d.Psi, ldn, d.T, Dp, nrun, st));
+        RC(pgl_activation(d.Xt, d.Tp, s->Wt + nf, ldn, d.Psi + nf, ldn, d.T, Dp, nrun, st));
         clk.toc(m);
         m = clk.tic(ST_PG, (double)d.T * nrun);
-        if (s->obs == 2) RC(pgl_k_gaussian_stats(d.Psi, ldn, s->bias, d.Y, ldn, s->inv_eta, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nrun, st));
-        else RC(pgl_k_pg_loglik(d.Psi, ldn, s->bias, d.Y, ldn, d.OK, 2 * ldn, d.OK + ldn, 2 * ldn, d.llpart, s->ll, i > 0, d.T, nrun, s->obs, s->xi, seed, sweep,
-                                (uint64_t)s->n0, d.elem0, st));
+        if (s->obs == 2) RC(pgl_k_gaussian_stats(d.Psi + nf, ldn, s->bias + nf, d.Y + nf, ldn, s->inv_eta + nf, d.OK + nf, 2 * ldn, d.OK + ldn + nf, 2 * ldn, d.llpart,
+                                                 s->ll + nf, i > 0, d.T, nrun, st));
+        else RC(pgl_k_pg_loglik(d.Psi + nf, ldn, s->bias + nf, d.Y + nf, ldn, d.OK + nf, 2 * ldn, d.OK + ldn + nf, 2 * ldn, d.llpart, s->ll + nf, i > 0, d.T, nrun,
+                                s->obs, s->xi, seed, sweep, (uint64_t)(s->n0 + nf), d.elem0, st));
         clk.toc(m);
         if (d.omega_override) {       // test hook: the reference fixtures inject omega
             if (hipMemcpy2DAsync(d.OK, (size_t)2 * ldn * sizeof(double), d.omega_override, (size_t)nloc * sizeof(double), (size_t)nloc * sizeof(double),
@@ -189,7 +192,7 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         // The output is small (2 nloc x (D+1)) and the contraction long (T): with few neurons it is a handful of 128 x 256 tiles -- 6
         // workgroups at N = 128, 42 on a 128-neuron shard of cfg3 -- each walking all of T.  So T is cut into S slices, one batch of the
         // GEMM each, whose partial sums go to the (still unused) J buffer and are added up in slice order by one small kernel.
-        // (a prefix run -- nrun < nloc -- contracts the Omega and the Kappa columns of its neurons as two pieces)
+        // (a partial run -- nrun < nloc -- contracts the Omega and the Kappa columns of its neurons as two pieces)
         const int npieces = nrun < nloc ? 2 : 1;
         const int Mp = nrun < nloc ? r_up(nrun, 2) : 2 * ldn;
         const long part = (long)2 * ldn * Dp;
@@ -211,8 +214,8 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         if (S > cap_any) S = cap_any;
         if (S > cap_this) S = cap_this;            // (a shard in several batches with a cramped buffer: never at D >= 128)
         for (int piece = 0; piece < npieces; ++piece) {
-            const double* Ap = d.OK + (long)piece * ldn;                 // columns [0, Mp) of Omega, then of Kappa
-            const long crow = (long)piece * ldn * Dp;                    // rows of the border: omega sums, then kappa sums
+            const double* Ap = d.OK + (long)piece * ldn + nf;            // columns [nf, nf + Mp) of Omega, then of Kappa
+            const long crow = ((long)piece * ldn + nf) * Dp;             // rows of the border: omega sums, then kappa sums
             if (S >= 2) {
                 const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
                 PglGemmArgs a{};
@@ -248,8 +251,8 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         c0 = s->c0_dense;
     }
 
-    for (int s0 = 0; s0 < nrun; s0 += nb) {
-        const int nbb = nb < nrun - s0 ? nb : nrun - s0;
+    for (int s0 = nf; s0 < nf + nrun; s0 += nb) {
+        const int nbb = nb < nf + nrun - s0 ? nb : nf + nrun - s0;
         // ---- likelihood Gram of neurons [s0, s0 + nbb)  (regression.py:251-252)
         if (s->obs == 2) {
             auto m = clk.tic(ST_GSCALE, 8.0 * nbb * D * (D + 1) / 2);

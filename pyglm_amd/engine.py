@@ -608,15 +608,15 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
     @_on_device
     def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None, nrun=0,
-              after_queue=None, readback=True):
+              after_queue=None, readback=True, nfirst=0):
         """regression.py:265-280 for every local neuron, as ONE call of pgl_sweep (include/pyglm_hip.h): the whole sweep is queued on the
         stream without a host synchronisation.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in natural form
         (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
         omega_override: list of (T, nloc) arrays replacing the PG draws (test hook: the reference fixtures inject omega).
         host_overlap: optional callable run on the host while the GPU works through the queue (seconds at full size), e.g. to draw the
         next sweep's permutations.
-        nrun: sweep only the first nrun local neurons (what one rank of a larger job would do, timed on this GPU -- bench.py's
-        scaling_proxy); the returned rows of the others are their input.
+        nrun, nfirst: sweep only local neurons [nfirst, nfirst + nrun) (what one rank of a larger job would do, timed on this GPU -- bench.py's
+        scaling_proxy times every shard of a G-rank job this way); the returned rows of the others are their input.
         after_queue: optional callable(engine) run right after the sweep has been queued, with the engine's device current -- the
         population model packs the new rows (packed_state) and starts its all_gather there, behind the sweep on the same stream.
         readback=False: the new (a, W, b) stay on the device (a_dev / W_dev / b_dev, packed_state); only ll and the status flags come
@@ -689,7 +689,7 @@ class GibbsEngine(object):
                             ptr(self.Jbuf), ptr(self.Mtab), ptr(self.Ac), ptr(self.hc), ptr(self.Tinv), ptr(self.G), ptr(self.Lws), ptr(self.Ut),
                             ptr(self.Wt_ws), ptr(self.d_idx), ptr(self.d_sign), ptr(self.d_cnt), ptr(self.batch_k), ptr(self.act), ptr(self.na),
                             ptr(i8[3]) if i8 else None, ptr(i8[4]) if i8 else None, ptr(i8[5]) if i8 else None,
-                            int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, None, 0, 0, 0, 0, 0, None)
+                            int(i8[6]) if i8 else 0, ptr(i8[7]) if i8 else None, ptr(i8[8]) if i8 else None, None, 0, 0, 0, 0, 0, 0, None)
             self._sweep_cache = (sig, sw, dsets)
         sw = self._sweep_cache[1]
         if ovs:
@@ -699,7 +699,7 @@ class GibbsEngine(object):
         sw.logodds, sw.c0_dense = ptr(self.logodds), ptr(self._c0_dense)
         sw.i8_norm = ptr(self._i8_norm) if i8 else None
         n_act = int(a.sum(axis=1).max()) if a.size else 0
-        sw.nrun, sw.all_deterministic = int(nrun), int(det.all())
+        sw.nrun, sw.nfirst, sw.all_deterministic = int(nrun), int(nfirst), int(det.all())
         sw.init_rows_bound = 1 + B * n_act
         sw.active_rows_bound = (1 + B * int(np.round(rho).sum(axis=1).max())) if det.all() else 0
         sw.flip_single_pass = int(self.flip_single_pass)
@@ -727,9 +727,16 @@ class GibbsEngine(object):
         status = hout[off_st:off_st + 4 * nloc].view(np.int32).copy()
         del keep
         if status.any():
+            # the reference's np.linalg.cholesky raises at the first such neuron (regression.py:369-370), with the neurons before it already
+            # updated.  Here the whole shard has been computed: the exception names every neuron concerned (global indices) and carries the
+            # shard's results, of which the rows of the other neurons are good; the caller's state is left as it was before the sweep
             bad = np.nonzero(status)[0]
-            raise np.linalg.LinAlgError("posterior system not positive definite for local neurons %s (flags %s)"
-                                        % (bad[:8].tolist(), status[bad[:8]].tolist()))
+            err = np.linalg.LinAlgError("posterior system not positive definite for neurons %s (local %s, flags %s)"
+                                        % ((bad[:8] + self.n0).tolist(), bad[:8].tolist(), status[bad[:8]].tolist()))
+            err.neurons = (bad + self.n0).tolist()
+            err.flags = status[bad].tolist()
+            err.state = (a_i.astype(bool), W_new, b_new) if readback else None
+            raise err
         return (a_i.astype(bool) if readback else None), W_new, b_new, self._ll_host_np(ll)       # (astype copies out of the staging buffer)
 
     @_on_device

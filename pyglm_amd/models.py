@@ -7,7 +7,7 @@ shard by postsynaptic neuron over the ranks of a torch.distributed process group
     rank r owns neurons [r*N/G, (r+1)*N/G)   -- its Y columns, its rows of (A, W, b); X is replicated.
     per sweep:  ONE all_gather_into_tensor of the shard's packed rows (W | b | eta | a as bytes), taken from the device buffers the
                 sweep updated and launched behind it on the stream (the network prior needs the full (A, W), models.py:230);
-                all_reduce of one fp64 scalar in log_likelihood().
+                all_reduce of the N per-neuron fp64 log-likelihoods (own entries, zeros elsewhere) in log_likelihood().
 Random inputs are keyed by (seed, sweep, global neuron), so results do not depend on the number of ranks.
 """
 import numpy as np
@@ -233,7 +233,9 @@ class NonlinearAutoregressiveModel(object):
             return ("deferred", packed)
         t0 = time.perf_counter()
         counts = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
-        maxc = max(hi - lo for lo, hi in counts)
+        # rows per rank in the gathered buffer: the largest shard (N not a multiple of the world size: smaller shards are padded with zero
+        # rows); _gather_min_rows (test hook) forces padding where every shard is equal -- e.g. on the one rank a one-GPU box has
+        maxc = max(max(hi - lo for lo, hi in counts), int(getattr(self, "_gather_min_rows", 0)))
         if nccl and not packed.is_cuda:
             packed = packed.to(self._comm_dev())
         if packed.shape[0] < maxc:
@@ -269,19 +271,26 @@ class NonlinearAutoregressiveModel(object):
         a, W, b = self._local_state()
         if self.engine_obs() == "gaussian":
             eng.set_noise([r.eta for r in self.regressions[self.n0:self.n1]])
-        ll = float(np.sum(eng.log_likelihood(a, W, b)))
+        ll_loc = np.asarray(eng.log_likelihood(a, W, b), dtype=np.float64).reshape(-1)       # one value per local neuron
         dist = _dist()
-        if dist is not None:
-            import time
-            import torch
-            t0 = time.perf_counter()
-            t = torch.tensor([ll], dtype=torch.float64)
-            if dist.get_backend() == "nccl":
-                t = t.to(self._comm_dev())
-            dist.all_reduce(t)            # the only collective on the likelihood path: one fp64 scalar
-            ll = float(t.item())
-            self.comm_seconds += time.perf_counter() - t0
-            self.collectives += 1
+        if dist is None:
+            return float(np.sum(ll_loc))
+        # the only collective on the likelihood path: ONE all_reduce -- of the N per-neuron values, each rank contributing its own entries and
+        # zeros elsewhere (x + 0 is exact, so the reduction's order cannot matter), then summed in neuron order on every rank: the total is
+        # the same to the last bit whatever the number of ranks (a scalar all_reduce of per-rank sums regroups the additions; 8 N bytes
+        # instead of 8 cost nothing on xGMI)
+        import time
+        import torch
+        t0 = time.perf_counter()
+        vec = np.zeros(self.N)
+        vec[self.n0:self.n1] = ll_loc
+        t = torch.from_numpy(vec)
+        if dist.get_backend() == "nccl":
+            t = t.to(self._comm_dev())
+        dist.all_reduce(t)
+        ll = float(np.sum(t.cpu().numpy()))
+        self.comm_seconds += time.perf_counter() - t0
+        self.collectives += 1
         return ll
 
     def _heldout_engine(self, datas):

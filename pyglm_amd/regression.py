@@ -5,6 +5,8 @@ that pokes `model.regressions[n].a[n] = True` or sets `reg.S_w = ...` keeps work
 path runs on the GPU: a population model batches its regressions through `pyglm_amd.engine.GibbsEngine`; a
 stand-alone regression (examples/bernoulli_regression.py style) builds a one-neuron engine on demand.
 """
+import ctypes
+
 import numpy as np
 import numpy.random as npr
 
@@ -86,6 +88,17 @@ class _SparseScalarRegressionBase(object):
         A[row], W[row], b[row] = a0, W0, np.asarray(b0).reshape(1)
         self._store = (A, W, b, row)
         self.__dict__.pop("_a", None), self.__dict__.pop("_W", None), self.__dict__.pop("_b", None)
+
+    def __getstate__(self):
+        """copy.copy / copy.deepcopy / pickle of a regression DETACH it from its population model: the copy owns its (a, W, b) again (the values
+        of its row) instead of aliasing -- or carrying along -- the model's (N, N, B) state arrays; device-side caches are not state.  A
+        model that deep-copies its regressions (get_state / set_state) adopts the copies into fresh arrays."""
+        d = dict(self.__dict__)
+        st = d.pop("_store", None)
+        if st is not None:
+            d["_a"], d["_W"], d["_b"] = st[0][st[3]].copy(), st[1][st[3]].copy(), st[2][st[3]].copy()
+        d["_engine_cache"] = d["_lik_engine_cache"] = None
+        return d
 
     # hyper-parameter setters broadcast scalars (:95-136).  The population model caches the natural-parameter terms of its regressions;
     # a version counter says whether they are still current.  It is bumped by every assignment AND by every read through the public
@@ -294,6 +307,30 @@ class _SparsePGRegressionBase(_SparseScalarRegressionBase):
 
     def kappa(self, X, y):
         return self.a_func(y) - self.b_func(y) / 2.0
+
+    def omega(self, X, y, seed=None, sweep=0):
+        """omega_t ~ PG(b(y_t), psi_t)  (:496-508): the activation on the GPU, then one draw per time bin from the device sampler
+        (pgl_pg_draw, which stands where the reference calls pypolyagamma's pgdrawvpar).  Returns a NumPy vector shaped like y.
+        The reference draws from per-thread samplers seeded once from NumPy's global stream (:476); here every draw has its own
+        counter-based stream keyed by (seed, sweep, neuron, time bin): seed=None takes a fresh seed from NumPy's global stream (so
+        np.random.seed(k) makes the call reproducible, and successive calls differ, as in the reference), an explicit (seed, sweep)
+        replays the draws a model sweep of that key makes for this neuron (the regression's row in its model, 0 when stand-alone)."""
+        import torch
+        from ._lib import call, ptr
+        X = self._flatten_X(X)
+        y = np.asarray(y)
+        assert y.shape == (X.shape[0], 1) or y.shape == (X.shape[0],)
+        psi = self.activation(X)
+        bshape = np.ascontiguousarray(np.broadcast_to(np.asarray(self.b_func(y.reshape(-1)), dtype=np.float64), psi.shape))
+        seed = int(npr.randint(2 ** 31)) if seed is None else int(seed)
+        neuron = 0 if self._store is None else int(self._store[3])
+        dev = self._lik_engine_cache[1].dev
+        with torch.cuda.device(dev):
+            zd, bd = torch.from_numpy(np.ascontiguousarray(psi)).to(dev), torch.from_numpy(bshape).to(dev)
+            out = torch.empty_like(zd)
+            call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), psi.size, seed, (int(sweep) << 32) | neuron, 0,
+                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            return out.cpu().numpy().reshape(y.shape)
 
 
 class SparseBernoulliRegression(_SparsePGRegressionBase):

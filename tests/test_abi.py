@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(lib, s), "libpyglm_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == declared_symbols()      # the ctypes table mirrors the header 1:1
-    assert _lib.load().pgl_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.load().pgl_abi_version() == _lib.ABI_VERSION == 11
     assert _lib.load().pgl_flip_kmax() == 512 and _lib.load().pgl_flip_window_blocks(5) == 64
     # host-side constants of the integer Gram: bits of the column norms per number of moduli, fewest moduli at the fp64 level
     lib = _lib.load()

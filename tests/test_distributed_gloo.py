@@ -72,6 +72,10 @@ def test_two_ranks_equal_one(tmp_path):
     a, b = np.load(one), np.load(two)
     for k in a.files:
         np.testing.assert_allclose(a[k], b[k], rtol=1e-12, atol=1e-12, err_msg=k)
+    # the log-likelihood total does not depend on the number of ranks in ANY bit: the ranks all_reduce the N per-neuron values (own entries,
+    # zeros elsewhere) and every rank sums them in neuron order (round 6; a scalar all_reduce regrouped the additions)
+    np.testing.assert_array_equal(a["lls"], b["lls"])
+    np.testing.assert_array_equal(a["held"], b["held"])
     assert a["A"].shape == (5, 5) and a["W"].shape == (5, 5, 2) and a["means"].shape == (400, 5)
     assert np.isclose(a["held"][0], a["held"][1], rtol=1e-12) and a["held"][0] == a["held"][3] and a["held"][2] < a["held"][0]
     assert np.all(np.isfinite(a["lls"]))

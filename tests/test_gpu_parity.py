@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import pyglm_oracle as orc
+from tests._pg_agree import assert_pg_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -50,17 +51,15 @@ def test_pg_draw_matches_oracle(torch_dev, zscale):
     got = out.cpu().numpy()
     want = orc.pg_draw(None, z, seed, stream, 17)
     assert np.all(np.isfinite(got)) and np.all(got > 0)
-    close = np.abs(got - want) <= 1e-12 * np.abs(want)
-    # libm vs OCML differ by ulps inside exp/log/erfc, which can flip an accept/reject on a knife edge: allow 1e-4
-    assert close.mean() >= 1 - 1e-4, "only %.6f of draws agree" % close.mean()
+    # libm vs OCML differ by ulps inside exp/log/erfc, which can flip an accept/reject on a knife edge: measured 0 of 3e7 (tests/_pg_agree.py)
+    assert_pg_agree(got, want)
     # integer b (negative-binomial shape): sum of b PG(1) draws on the same stream
     b = rng.integers(0, 5, n).astype(np.float64)
     bd = torch.from_numpy(b).cuda()
     call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, seed, stream, 0, None)
     got = out.cpu().numpy()
     want = orc.pg_draw(b, z, seed, stream, 0)
-    close = np.abs(got - want) <= 1e-12 * np.abs(want) + 1e-300
-    assert close.mean() >= 1 - 3e-4
+    assert_pg_agree(got, want)
     assert np.all(got[b == 0] == 0)
 
 
@@ -154,8 +153,7 @@ def test_device_pg_alternate_sampler_matches_oracle(torch_dev, b):
     got = out.cpu().numpy()
     want = orc.pg_draw(np.full(n, b), z, 11, orc.stream_id(6, 2), 3)
     assert np.all(np.isfinite(got)) and np.all(got > 0)
-    close = np.abs(got - want) <= 1e-12 * np.abs(want)
-    assert close.mean() >= 1 - 2e-4 * max(1.0, b), "only %.6f of draws agree" % close.mean()
+    assert_pg_agree(got, want)
 
 
 def test_device_pg_real_shapes_match_oracle(torch_dev):
@@ -175,8 +173,7 @@ def test_device_pg_real_shapes_match_oracle(torch_dev):
     got = out.cpu().numpy()
     want = orc.pg_draw(b, z, 9, orc.stream_id(2, 3), 5)
     assert got[0] == 0.0 and np.all(np.isfinite(got)) and np.all(got[1:] > 0)
-    close = np.abs(got - want) <= 1e-8 * np.abs(want) + 1e-300
-    assert close.mean() >= 1 - 2e-3, "only %.6f of draws agree" % close.mean()
+    assert_pg_agree(got, want, tol=1e-8)
 
 
 @pytest.mark.parametrize("b", [13.0, 50.0, 64.0])
@@ -195,8 +192,7 @@ def test_device_pg_integer_shapes_are_exact_sums(torch_dev, b):
     call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), n, 3, orc.stream_id(4, 1), 2, None)
     got = out.cpu().numpy()
     want = orc.pg_draw(np.full(n, b), z, 3, orc.stream_id(4, 1), 2)
-    close = np.abs(got - want) <= 1e-12 * np.abs(want)
-    assert close.mean() >= 1 - 1e-4 * b, "only %.6f of draws agree" % close.mean()
+    assert_pg_agree(got, want)
     from tests.test_oracle_pg import pg_mean, pg_var
     om = _device_pg(b, 2.0, 200000, 29, orc.stream_id(int(b), 7))
     assert abs(om.mean() - pg_mean(b, 2.0)) < 5 * np.sqrt(pg_var(b, 2.0) / om.size)
@@ -370,6 +366,11 @@ def _check_logodds(eng, outs, rows=None):
         assert np.isnan(lo[n, len(trace):]).all()                          # no proposals beyond the trace
 
 
+def _with_state(r, a, W, b):
+    r.a, r.W, r.b = a, W, b
+    return r
+
+
 def _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z):
     outs = []
     for n in range(N):
@@ -398,13 +399,11 @@ def test_sweep_vs_oracle(torch_dev, N, B, T, rho, batch):
     eng.keep_logodds = True
     a1, W1, b1, _ = eng.sweep(a, W, b, rho_a, Jw, hw, Jb, hb, c0, perm, u, z, seed=123, sweep=4)
     omegas = eng.datasets[0].OK[:T, :N].cpu().numpy()
-    # the PG draws themselves: against the oracle on the same stream
-    for n in (0, N - 1):
-        r = regs[n]
-        r.a, r.W, r.b = a[n], W[n], b[n:n + 1]
-        want = orc.pg_draw(None, r.activation(X), 123, orc.stream_id(n, 4))
-        close = np.abs(omegas[:, n] - want) <= 1e-12 * want
-        assert close.mean() >= 1 - 2e-3
+    # the PG draws themselves: the device's, from ITS activation (MFMA summation order), against the oracle's from NumPy's, on the same
+    # stream -- every neuron (measured: 0 of 2.9e6 such draws differ although 72 % of the activations are not bit-equal, tests/_pg_agree.py)
+    want = np.column_stack([orc.pg_draw(None, _with_state(regs[n], a[n], W[n], b[n:n + 1]).activation(X), 123, orc.stream_id(n, 4))
+                            for n in range(N)])
+    assert_pg_agree(omegas, want, what="omega of a sweep (N=%d, T=%d)" % (N, T))
     outs = _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z)
     for n, (ao, Wo, bo, trace) in enumerate(outs):
         np.testing.assert_array_equal(a1[n], ao, err_msg="adjacency row %d" % n)
@@ -670,12 +669,17 @@ def test_prefix_run_equals_the_same_neurons_of_a_full_sweep(torch_dev, gram):
     eng = _engine(N, B, gram=gram, batch=4)
     eng.add_data(Y, basis=basis)
     full = eng.sweep(a, W, b, *hyp, perm, u, z, seed=9, sweep=2)
-    for k in (5, 8):
-        part = eng.sweep(a, W, b, *hyp, perm, u, z, seed=9, sweep=2, nrun=k)
+    # ... and any range [f, f + k) of them (round 6: pgl_sweep_t.nfirst -- bench.py's scaling_proxy times EVERY shard of a G-rank job, not only
+    # the first): batched from f on, as the rank owning that shard would batch it; the rows outside stay as they were
+    for f, k in ((0, 5), (0, 8), (4, 6), (6, 7), (2, 11), (12, 1)):
+        part = eng.sweep(a, W, b, *hyp, perm, u, z, seed=9, sweep=2, nrun=k, nfirst=f)
         for x, y, x0 in zip(part[:3], full[:3], (a, W, b)):
-            np.testing.assert_array_equal(x[:k], y[:k])
-            np.testing.assert_array_equal(x[k:], x0[k:])
-        np.testing.assert_array_equal(part[3][:k], full[3][:k])
+            np.testing.assert_array_equal(x[f:f + k], y[f:f + k])
+            np.testing.assert_array_equal(x[:f], x0[:f])
+            np.testing.assert_array_equal(x[f + k:], x0[f + k:])
+        np.testing.assert_array_equal(part[3][f:f + k], full[3][f:f + k])
+    with pytest.raises(Exception):
+        eng.sweep(a, W, b, *hyp, perm, u, z, seed=9, sweep=2, nrun=3, nfirst=5)          # (odd start: refused by pgl_sweep)
 
 
 def test_two_windows_per_pass_give_the_bits_of_one_pass_per_window(torch_dev):

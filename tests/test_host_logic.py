@@ -533,6 +533,30 @@ def test_chain_state_lives_in_three_model_arrays_and_the_regressions_see_views()
     assert m.adjacency[0].all()
 
 
+def test_copies_of_an_adopted_regression_are_detached():
+    """copy.copy / copy.deepcopy / pickle of a regression that a model has adopted give a regression that owns its (a, W, b) (the
+    row's values): assigning to the copy does not overwrite the model's row, and a pickled regression does not carry the (N, N, B) store."""
+    import copy
+    import pickle
+    from pyglm_amd.models import SparseBernoulliGLM
+    from tests._oracle_engine import OracleEngine
+    np.random.seed(8)
+    N, B = 40, 3
+    m = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=2.0, mu_b=-1.0), seed=3, engine_factory=OracleEngine)
+    r = m.regressions[5]
+    W5 = m.weights[5].copy()
+    for c in (copy.copy(r), copy.deepcopy(r), pickle.loads(pickle.dumps(r))):
+        assert c._store is None and c.W.shape == (N, B) and c.b.shape == (1,)
+        np.testing.assert_array_equal(c.W, W5)
+        np.testing.assert_array_equal(c.a, m.adjacency[5])
+        c.W = np.full((N, B), 9.0)
+        c.a[:] = True
+        np.testing.assert_array_equal(m.weights[5], W5)
+        assert c.rho.shape == (N,) and c.S_w.shape == (N, B, B)
+    assert len(pickle.dumps(r)) < 0.2 * len(pickle.dumps(m._adopt_state()[1]))      # one row + hyper-parameters, not the model's arrays
+    assert r._store is not None and r.W.base is m._adopt_state()[1]                  # the original stays a view
+
+
 def test_counter_files_are_tied_to_the_kernel_sources():
     """committed hardware-counter summaries record the hash of the kernel sources they were taken on (pyglm_amd._lib.source_hash); bench.py
     quotes them only on a match.  The hash is stable, 16 hex digits, and moves with the sources."""

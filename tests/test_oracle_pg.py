@@ -111,7 +111,7 @@ def gamma_series_sample(b, z, n, rng, K=600):
     return out / (2 * np.pi ** 2)
 
 
-REAL_B = [0.3, 1.0, 1.02, 1.5, 2.0, 2.5, 7.0, 12.0, 13.7, 50.0, 63.99, 70.5]
+REAL_B = [0.3, 1.0, 1.0 + 1e-7, 1.02, 1.5, 2.0, 2.5, 3.0 - 1e-6, 7.0, 12.0, 13.7, 50.0, 63.99, 70.5]
 Z_GRID = [0.0, 0.3, 2.0, 6.0, 20.0, 40.0]
 
 
@@ -130,6 +130,34 @@ def test_pg_real_shape_moments_and_laplace(b):
         for t in (0.5 / m, 2.0 / m):                     # arguments on the scale of the distribution
             g = np.exp(-t * om)
             assert abs(g.mean() - pg_laplace(b, z, t)) < 5 * g.std() / np.sqrt(n), (b, z, t)
+
+
+NEAR_INTEGER = [(1.0 + 2.2e-16, 2.0), (1.0 + 2.2e-16, 5.0), (3.0 + 4.4e-16, 5.0), (1.0 + 1e-14, 7.0), (1.0 + 1e-13, 33.0),
+                (2.0 - 2.2e-16, 0.0), (1.0 + 1e-9, 60.0), (1.0 + 1.0001e-9, 60.0), (1.1 * 1.1 / 1.21 + 4.0, 1.0)]
+
+
+@pytest.mark.timeout(60)
+@pytest.mark.parametrize("b,z", NEAR_INTEGER)
+def test_pg_shapes_at_rounding_distance_from_an_integer_terminate(b, z):
+    """with h - 1 at rounding level the truncated-gamma proposal's 1 - c rounded to 0 and nothing was ever accepted (the draw
+    spun).  Now 1 - c is formed without the subtraction, shapes within 1e-9 of an integer ARE that integer (same draws as the integer:
+    asserted), and every loop is bounded."""
+    n = 50000
+    om = orc.pg_draw(np.full(n, b), np.full(n, z), seed=8, stream=orc.stream_id(1, 1))
+    assert np.all(np.isfinite(om)) and np.all(om > 0)
+    bi = np.round(b)
+    m, v = pg_mean(bi, z), pg_var(bi, z)
+    assert abs(om.mean() - m) < 5 * np.sqrt(v / n)
+    if abs(b - bi) < 1e-9:
+        np.testing.assert_array_equal(om, orc.pg_draw(np.full(n, bi), np.full(n, z), seed=8, stream=orc.stream_id(1, 1)))
+
+
+@pytest.mark.timeout(60)
+def test_pg_non_finite_activation_gives_nan_not_a_hang():
+    for b in (0.5, 1.0, 1.5, 7.25, 80.0):
+        for z in (np.nan, np.inf, -np.inf):
+            assert np.all(np.isnan(orc.pg_draw(np.full(64, b), np.full(64, z), seed=1, stream=0)))
+    assert orc.pg_draw(np.zeros(3), np.full(3, np.nan), seed=1, stream=0).tolist() == [0, 0, 0]      # PG(0, .) = 0 whatever z
 
 
 @pytest.mark.parametrize("b,z", [(0.3, 0.0), (0.3, 6.0), (1.05, 1.0), (1.5, 0.0), (1.95, 8.0), (2.5, 2.0), (13.7, 0.3), (50.0, 20.0)])
