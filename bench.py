@@ -287,7 +287,7 @@ def gather_cost_one_rank(model, eng, reps=3):
                 h = model._gather_start(eng.packed_state())
             rows = model._gather_finish(h)
             ms.append((time.perf_counter() - t0) * 1e3)
-        assert rows[1].shape == (model.N, model.N, model.B)
+        assert rows[1].shape == (model.N, model.N * model.B)
         pay = int(h[1].numel())
         return {"available": True, "ms": float(np.median(ms[1:])), "ms_all": [round(x, 3) for x in ms], "payload_bytes": pay, "backend": "nccl", "world": 1,
                 "what": "packed_state (device) + all_gather_into_tensor + device->host copy of all N rows + unpack, median of %d after one warm-up" % reps,

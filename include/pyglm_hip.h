@@ -297,6 +297,12 @@ typedef struct {
 } pgl_sweep_t;
 
 int pgl_sweep_dims(int N, int B, int nloc, int* Dp, int* ldn, int* ldj);
+/* Sufficient statistics of a shard's rows for the network prior: out[n] = [count, sum_m w_m (B), sum_m w_m w_m' (B x B, row-major)] over the
+ * active presynaptic neurons m != n0 + n of local neuron n -- what pyglm/networks.py:132-149 needs of W[A & ~eye] (an NIW update is a function
+ * of the count, the sum and the sum of outer products).  a [nloc][N] (0/1), W [nloc][N*B] as pgl_sweep leaves them; out [nloc][1 + B + B*B].
+ * Every entry is accumulated over m in ascending order by one thread: a neuron's numbers do not depend on the shard it is in.  The ranks
+ * exchange these 1 + B + B^2 doubles per neuron with their rows, so that no rank walks the N^2 B doubles of the gathered state. */
+int pgl_row_stats(const int* a, const double* W, double* out, int N, int B, int nloc, int n0, void* hip_stream);
 int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_stream);
 /* copies the shard's state to host buffers (any may be NULL) and waits for the stream: a [nloc][N], W [nloc][D], b, ll, status [nloc].
  * The read-backs of pyglm/models.py:54-64 (weights / adjacency / biases) for a non-Python binder. */

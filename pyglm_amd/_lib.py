@@ -85,6 +85,7 @@ SIGNATURES = {
     "pgl_flip_apply_window": [ctypes.POINTER(FlipState), c_i, c_p],
     "pgl_flip_visit_order": [ctypes.POINTER(FlipState), c_p, c_l, c_l, c_p],
     "pgl_flip_decide": [ctypes.POINTER(FlipState), c_i, c_p],
+    "pgl_row_stats": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "pgl_sweep_dims": [c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
     "pgl_sweep": [ctypes.POINTER(Sweep), c_u64, c_u64, c_p],
     "pgl_get_state": [ctypes.POINTER(Sweep), c_p, c_p, c_p, c_p, c_p, c_p],

@@ -54,6 +54,11 @@ extern "C" {
 int pgl_abi_version(void) { return PGL_ABI_VERSION; }
 const char* pgl_last_error(void) { return g_err; }
 
+int pgl_row_stats(const int* a, const double* W, double* out, int N, int B, int nloc, int n0, void* st) {
+    PGL_CHECK_ARG(a && W && out && N > 0 && B > 0 && B <= 32 && nloc > 0 && n0 >= 0);
+    return pgl_k_row_stats(a, W, out, N, B, nloc, n0, ST(st));
+}
+
 int pgl_philox_words(uint64_t seed, uint32_t purpose, uint32_t j, uint64_t elem0, uint64_t stream, uint32_t* out, size_t n, void* st) {
     PGL_CHECK_ARG(out != nullptr || n == 0);
     return pgl_k_philox_words(seed, purpose, j, elem0, stream, out, n, ST(st));

@@ -107,6 +107,7 @@ struct PglCholState {
 // kernels' host launchers (defined next to their kernels)
 int pgl_k_philox_words(uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint32_t*, size_t, hipStream_t);
 int pgl_k_pg_draw(const double*, const double*, double*, size_t, uint64_t, uint64_t, uint64_t, hipStream_t);
+int pgl_k_row_stats(const int* a, const double* W, double* out, int N, int B, int nloc, int n0, hipStream_t st);
 int pgl_k_pg_loglik(double*, long, const double*, const double*, long, double*, long, double*, long, double*, double*, int, int, int, int, double,
                     uint64_t, uint64_t, uint64_t, uint64_t, hipStream_t);
 int pgl_k_pg_loglik_nblk(int);

@@ -266,6 +266,52 @@ int pgl_k_pg_draw(const double* b, const double* z, double* out, size_t len, uin
     return PGL_OK;
 }
 
+// ------------------------------------------------------------------ sufficient statistics of a shard's rows for the network prior
+// pyglm/networks.py:132-149 hands W[A & ~eye] (all active off-diagonal weight vectors of the population) to an NIW Gaussian, whose update needs
+// only their count, sum and sum of outer products.  Per postsynaptic neuron n (one workgroup): out[n] = [count, sum_m w_m (B), sum_m w_m w_m' (B x B)]
+// over the ACTIVE presynaptic m != n0 + n -- 1 + B + B^2 doubles that ride along in the row a rank contributes to the per-sweep all_gather, so
+// that no rank walks the N^2 B doubles of the gathered state.  Every entry is accumulated over m = 0, 1, 2, ... by ONE thread: the same
+// additions in the same order whatever the shard.
+constexpr int RS_CHUNK = 64;
+__global__ __launch_bounds__(256) void row_stats_kernel(const int* __restrict__ a, const double* __restrict__ W, double* __restrict__ out, int N, int B, int n0) {
+    const int n = blockIdx.x, tid = threadIdx.x, self = n0 + n;
+    const int ne = 1 + B + B * B;
+    __shared__ double w[RS_CHUNK * 32];
+    __shared__ int act[RS_CHUNK];
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};             // entries tid, tid + 256, ... (ne <= 1 + 32 + 1024)
+    const double* Wn = W + (long)n * N * B;
+    for (int m0 = 0; m0 < N; m0 += RS_CHUNK) {
+        const int cnt = RS_CHUNK < N - m0 ? RS_CHUNK : N - m0;
+        for (int i = tid; i < cnt * B; i += 256) w[i] = Wn[(long)m0 * B + i];
+        if (tid < cnt) act[tid] = a[(long)n * N + m0 + tid] != 0 && (m0 + tid) != self;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int e = tid + 256 * k;
+            if (e >= ne) break;
+            const int i1 = e <= B ? e - 1 : (e - 1 - B) / B, i2 = e <= B ? -1 : (e - 1 - B) % B;
+            double s = acc[k];
+            for (int i = 0; i < cnt; ++i) {
+                if (!act[i]) continue;
+                s += e == 0 ? 1.0 : i2 < 0 ? w[i * B + i1] : w[i * B + i1] * w[i * B + i2];
+            }
+            acc[k] = s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int e = tid + 256 * k;
+        if (e < ne) out[(long)n * ne + e] = acc[k];
+    }
+}
+
+int pgl_k_row_stats(const int* a, const double* W, double* out, int N, int B, int nloc, int n0, hipStream_t st) {
+    hipLaunchKernelGGL(row_stats_kernel, dim3(nloc), dim3(256), 0, st, a, W, out, N, B, n0);
+    PGL_CHECK_LAUNCH();
+    return PGL_OK;
+}
+
 int pgl_k_pg_loglik(double* Psi, long ldpsi, const double* bias, const double* Y, long ldy, double* Omega, long ldo, double* Kappa, long ldk,
                     double* llpart, double* ll_out, int accumulate, int T, int nloc, int obs, double xi, uint64_t seed, uint64_t sweep,
                     uint64_t neuron0, uint64_t elem0, hipStream_t st) {

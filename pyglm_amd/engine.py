@@ -608,7 +608,7 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
     @_on_device
     def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None, nrun=0,
-              after_queue=None, readback=True, nfirst=0):
+              after_queue=None, readback=True, nfirst=0, copy=True):
         """regression.py:265-280 for every local neuron, as ONE call of pgl_sweep (include/pyglm_hip.h): the whole sweep is queued on the
         stream without a host synchronisation.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in natural form
         (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
@@ -620,7 +620,9 @@ class GibbsEngine(object):
         after_queue: optional callable(engine) run right after the sweep has been queued, with the engine's device current -- the
         population model packs the new rows (packed_state) and starts its all_gather there, behind the sweep on the same stream.
         readback=False: the new (a, W, b) stay on the device (a_dev / W_dev / b_dev, packed_state); only ll and the status flags come
-        back: returns (None, None, None, ll)."""
+        back: returns (None, None, None, ll).
+        copy=False: the returned a (int32), W, b are VIEWS of the engine's pinned read-back buffer, valid until its next sweep -- for a
+        caller that stores them into arrays of its own right away (the population model: one pass over 42 MB at N = 1024 instead of three)."""
         nloc, N, B, D = self.nloc, self.N, self.B, self.D
         if self.likelihood_only or self.design_only:
             raise _lib.PglError("this engine was built without sweep buffers (likelihood_only / design_only)")
@@ -721,8 +723,10 @@ class GibbsEngine(object):
              ctypes.c_void_p(hp + off_b) if readback else None, ctypes.c_void_p(hp + off_ll), ctypes.c_void_p(hp + off_st), st)
         self.wait_seconds += time.perf_counter() - t_wait
         a_i = hout[off_a:off_a + 4 * nloc * N].view(np.int32).reshape(nloc, N) if readback else None
-        W_new = hout[off_W:off_W + 8 * nloc * D].view(np.float64).reshape(nloc, N, B).copy() if readback else None
-        b_new = hout[off_b:off_b + 8 * nloc].view(np.float64).copy() if readback else None
+        W_new = hout[off_W:off_W + 8 * nloc * D].view(np.float64).reshape(nloc, N, B) if readback else None
+        b_new = hout[off_b:off_b + 8 * nloc].view(np.float64) if readback else None
+        if readback and copy:
+            W_new, b_new = W_new.copy(), b_new.copy()
         ll = hout[off_ll:off_ll + 8 * nloc].view(np.float64).copy()
         status = hout[off_st:off_st + 4 * nloc].view(np.int32).copy()
         del keep
@@ -735,20 +739,32 @@ class GibbsEngine(object):
                                         % ((bad[:8] + self.n0).tolist(), bad[:8].tolist(), status[bad[:8]].tolist()))
             err.neurons = (bad + self.n0).tolist()
             err.flags = status[bad].tolist()
-            err.state = (a_i.astype(bool), W_new, b_new) if readback else None
+            err.state = (a_i.astype(bool), W_new.copy(), b_new.copy()) if readback else None
             raise err
+        if readback and not copy:
+            return a_i, W_new, b_new, self._ll_host_np(ll)
         return (a_i.astype(bool) if readback else None), W_new, b_new, self._ll_host_np(ll)       # (astype copies out of the staging buffer)
 
     @_on_device
+    def row_stats(self):
+        """[count, sum w, sum w w'] over the active off-diagonal weight vectors of every local neuron's row, (nloc, 1 + B + B^2) on the device,
+        from the state the last sweep left there (pgl_row_stats): what the network prior needs of this shard (networks.py:132-149).
+        Queued on the current stream (behind the sweep)."""
+        out = torch.empty((self.nloc, 1 + self.B + self.B * self.B), dtype=F64, device=self.dev)
+        call("pgl_row_stats", ptr(self.a_dev), ptr(self.W_dev), ptr(out), self.N, self.B, self.nloc, self.n0, self._st())
+        return out
+
+    @_on_device
     def packed_state(self):
-        """the shard's chain state as the sweep left it on the device, one row of bytes per neuron: W | b | eta (0) | a (models.state_row_layout)
-        -- what a rank contributes to the per-sweep all_gather.  Queued on the current stream (behind the sweep)."""
+        """the shard's chain state as the sweep left it on the device, one row of bytes per neuron: W | b | eta (0) | row statistics | a
+        (models.state_row_layout) -- what a rank contributes to the per-sweep all_gather.  Queued on the current stream (behind the sweep)."""
         from .models import state_row_layout
-        ob, oe, oa, rb = state_row_layout(self.N, self.B)
+        ob, oe, os_, oa, rb = state_row_layout(self.N, self.B)
         nl = self.nloc
         p = torch.zeros((nl, rb), dtype=torch.uint8, device=self.dev)
         p[:, :ob] = self.W_dev.view(torch.uint8).view(nl, ob)
         p[:, ob:oe] = self.b_dev.view(torch.uint8).view(nl, 8)
+        p[:, os_:oa] = self.row_stats().view(torch.uint8).view(nl, oa - os_)
         p[:, oa:oa + self.N] = self.a_dev.to(torch.uint8)
         return p
 

@@ -30,9 +30,31 @@ def _dist():
 
 def state_row_layout(N, B):
     """byte layout of one neuron's row of the packed state the ranks exchange: W (N*B doubles) | b (1 double) | eta (1 double: noise variance,
-    Gaussian model; 0 otherwise) | a (N bytes, padded to a multiple of 8)  ->  (offset of b, of eta, of a, bytes per row)"""
+    Gaussian model; 0 otherwise) | row statistics (1 + B + B^2 doubles: count, sum and sum of outer products of the row's active off-diagonal
+    weight vectors -- the network prior's sufficient statistics, networks.py:132-149) | a (N bytes, padded to a multiple of 8)
+    ->  (offset of b, of eta, of the statistics, of a, bytes per row)"""
     D = N * B
-    return 8 * D, 8 * D + 8, 8 * D + 16, 8 * D + 16 + -(-N // 8) * 8
+    os_ = 8 * D + 16
+    oa = os_ + 8 * (1 + B + B * B)
+    return 8 * D, 8 * D + 8, os_, oa, oa + -(-N // 8) * 8
+
+
+def host_row_stats(a, W, n0):
+    """the statistics pgl_row_stats forms on the device, on the host: [count, sum w, sum w w'] over the active presynaptic m != n0 + n of every row
+    n of a (n, N) / W (n, N, B) -- for state that never was on a GPU (a network resampled from user-supplied (A, W), the CPU test engine)"""
+    a = np.array(a, dtype=bool)
+    n, N = a.shape
+    B = W.shape[-1]
+    r = np.arange(n)
+    ok = n0 + r < N
+    a[r[ok], n0 + r[ok]] = False
+    out = np.empty((n, 1 + B + B * B))
+    for i in range(n):                       # row by row: a row's numbers must not depend on how many rows are handed in together
+        Wm = np.asarray(W[i], dtype=np.float64)[a[i]]
+        out[i, 0] = Wm.shape[0]
+        out[i, 1:1 + B] = Wm.sum(axis=0)
+        out[i, 1 + B:] = Wm.T.dot(Wm).reshape(-1)
+    return out
 
 
 def shard_bounds(N, world, rank):
@@ -83,6 +105,7 @@ class NonlinearAutoregressiveModel(object):
             self.seed = int(t.item())
         self._adopt_state()
         self.sweeps_done = 0
+        self._fresh_stats = self._stats_kept = None      # per-row statistics for the network prior (resample_regressions -> resample_network)
         self.comm_seconds = 0.0        # wall time this rank has spent inside collectives (all_gather of rows, scalar all_reduce)
         self.collectives = 0           # collectives issued by this rank (one per sweep + one per log_likelihood())
 
@@ -165,9 +188,12 @@ class NonlinearAutoregressiveModel(object):
         return A[self.n0:self.n1], W[self.n0:self.n1], b[self.n0:self.n1, 0]
 
     def _store_rows(self, lo, hi, a, W, b):
-        """rows [lo, hi) of the chain state <- (a, W, b): three array assignments (the regressions' a / W / b are views of these arrays)"""
+        """rows [lo, hi) of the chain state <- (a, W, b): three array assignments (the regressions' a / W / b are views of these arrays).
+        a may be boolean or 0/1 integers / bytes, W (rows, N, B) or (rows, N*B), contiguous or strided: one pass over each"""
         A_, W_, b_ = self._adopt_state()
-        A_[lo:hi], W_[lo:hi], b_[lo:hi, 0] = a, W, np.asarray(b).reshape(-1)
+        A_[lo:hi] = a
+        W_[lo:hi].reshape(hi - lo, -1)[...] = np.asarray(W).reshape(hi - lo, -1) if getattr(W, "ndim", 2) == 3 else W
+        b_[lo:hi, 0] = np.asarray(b).reshape(-1)
 
     def _gather_rows(self, arr):
         """all_gather of per-neuron rows over the shard axis (ranks may own different counts)"""
@@ -198,26 +224,31 @@ class NonlinearAutoregressiveModel(object):
         return out
 
     # ---- the per-sweep exchange: one packed all_gather
-    def _pack_rows_host(self, a, W, b, eta=None):
-        """host (a, W, b[, eta]) of the local rows -> packed uint8 rows (state_row_layout)"""
-        ob, oe, oa, rb = state_row_layout(self.N, self.B)
+    def _pack_rows_host(self, a, W, b, eta=None, stats=None):
+        """host (a, W, b[, eta]) of the local rows and their statistics -> packed uint8 rows (state_row_layout)"""
+        ob, oe, os_, oa, rb = state_row_layout(self.N, self.B)
         nl = a.shape[0]
         buf = np.zeros((nl, rb), dtype=np.uint8)
         buf[:, :ob] = np.ascontiguousarray(W, dtype=np.float64).reshape(nl, -1).view(np.uint8)
         buf[:, ob:oe] = np.ascontiguousarray(b, dtype=np.float64).reshape(nl, 1).view(np.uint8)
         if eta is not None:
-            buf[:, oe:oa] = np.ascontiguousarray(eta, dtype=np.float64).reshape(nl, 1).view(np.uint8)
+            buf[:, oe:os_] = np.ascontiguousarray(eta, dtype=np.float64).reshape(nl, 1).view(np.uint8)
+        if stats is not None:
+            buf[:, os_:oa] = np.ascontiguousarray(stats, dtype=np.float64).reshape(nl, -1).view(np.uint8)
         buf[:, oa:oa + self.N] = np.asarray(a).astype(np.uint8)
         return buf
 
     def _unpack_rows(self, buf):
-        ob, oe, oa, rb = state_row_layout(self.N, self.B)
+        """-> (a, W, b, eta, row statistics) of the rows in buf (n, row bytes): a (n, N) as bytes and W (n, N*B) are strided VIEWS of buf -- the
+        caller stores them into the model's arrays in one pass (_store_rows) --, b, eta and the statistics small copies"""
+        ob, oe, os_, oa, rb = state_row_layout(self.N, self.B)
         n = buf.shape[0]
-        W = np.ascontiguousarray(buf[:, :ob]).view(np.float64).reshape(n, self.N, self.B)
-        b = np.ascontiguousarray(buf[:, ob:oe]).view(np.float64).reshape(n)
-        eta = np.ascontiguousarray(buf[:, oe:oa]).view(np.float64).reshape(n)
-        a = buf[:, oa:oa + self.N].astype(bool)
-        return a, W, b, eta
+        W = buf[:, :ob].view(np.float64)
+        b = buf[:, ob:oe].view(np.float64).reshape(n).copy()
+        eta = buf[:, oe:os_].view(np.float64).reshape(n).copy()
+        stats = buf[:, os_:oa].view(np.float64).copy()
+        a = buf[:, oa:oa + self.N]
+        return a, W, b, eta, stats
 
     def _gather_start(self, packed):
         """packed: torch uint8 (local rows, row bytes), on the shard's GPU or on the host.  Starts ONE all_gather_into_tensor of it (ranks
@@ -249,15 +280,27 @@ class NonlinearAutoregressiveModel(object):
         return work, out, counts, maxc, packed
 
     def _gather_finish(self, handle):
-        """-> (A, W, b, eta) of ALL neurons as host arrays"""
+        """-> (A, W, b, eta, row statistics) of ALL neurons as host arrays"""
         import time
         if handle[0] == "deferred":
             handle = self._gather_start(handle[1].cpu())         # (the wait for the sweep is the sweep's time, not the collective's)
         t0 = time.perf_counter()
         work, out, counts, maxc, _keep = handle
         work.wait()
-        host = out.cpu().numpy()
-        rows = np.concatenate([host[r * maxc: r * maxc + (hi - lo)] for r, (lo, hi) in enumerate(counts)], axis=0)
+        if out.is_cuda:
+            # into a pinned buffer kept across sweeps (a fresh pageable 43 MB array per sweep costs several times the transfer)
+            import torch
+            hb = getattr(self, "_gather_host", None)
+            if hb is None or hb.shape != out.shape:
+                hb = self._gather_host = torch.empty(out.shape, dtype=torch.uint8).pin_memory()
+            hb.copy_(out)
+            host = hb.numpy()
+        else:
+            host = out.numpy()
+        if all(hi - lo == maxc for lo, hi in counts):
+            rows = host                                    # equal shards, no padding: the gathered buffer IS the N rows
+        else:
+            rows = np.concatenate([host[r * maxc: r * maxc + (hi - lo)] for r, (lo, hi) in enumerate(counts)], axis=0)
         self.comm_seconds += time.perf_counter() - t0
         return self._unpack_rows(rows)
 
@@ -410,11 +453,14 @@ class NonlinearAutoregressiveModel(object):
         if exchange and not gaussian and hasattr(self.engine, "packed_state"):
             # the shard's new rows never visit the host on their own: packed from the sweep's device buffers, gathered, read back once
             kw.update(after_queue=lambda eng: handle.append(self._gather_start(eng.packed_state())), readback=False)
+        if hasattr(self.engine, "_hout_np"):
+            kw["copy"] = False             # (the rows are stored into the model's arrays below, before the engine is used again)
         a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done, **kw)
         if handle:
             self.sweeps_done += 1
-            A_all, W_all, b_all, _ = self._gather_finish(handle[0])
+            A_all, W_all, b_all, _, stats_all = self._gather_finish(handle[0])
             self._store_rows(0, self.N, A_all, W_all, b_all)
+            self._fresh_stats = stats_all
             return
         if gaussian:
             # noise variances (regression.py:433-445): residual sums of squares under the NEW weights from the device, gamma draws
@@ -427,19 +473,32 @@ class NonlinearAutoregressiveModel(object):
                 alpha, beta = r.eta_posterior(T_total, sse[i])
                 eta[i] = 1.0 / (make_gamma_draws(self.seed, self.sweeps_done, [self.n0 + i], alpha)[0] * (1.0 / beta))
         self.sweeps_done += 1
+        # the rows' sufficient statistics for the network prior (networks.py:132-149), from the state the sweep left on the device
+        stats = None
+        if hasattr(getattr(self, "network", None), "weight_blocks"):
+            stats = self.engine.row_stats().cpu().numpy() if hasattr(self.engine, "row_stats") else host_row_stats(a, W, self.n0)
         if self._shard_override:
+            # (only this shard's rows move: the statistics of the others are formed once and kept -- bench.py --neurons, tools)
+            keep = getattr(self, "_stats_kept", None)
+            if stats is not None:
+                if keep is None:
+                    A_, W_, _ = self._adopt_state()
+                    keep = self._stats_kept = host_row_stats(A_, W_, 0)
+                keep[self.n0:self.n1] = stats
             self._store_rows(self.n0, self.n1, a, W, b)
+            self._fresh_stats = keep if stats is not None else None
             if gaussian:
                 for i, r in enumerate(regs):
                     r.eta = float(eta[i])
             return
         if not exchange:
-            A_all, W_all, b_all, eta_all = a, W, b, (eta if gaussian else None)
+            A_all, W_all, b_all, eta_all, stats_all = a, W, b, (eta if gaussian else None), stats
         else:
             import torch
-            packed = torch.from_numpy(self._pack_rows_host(a, W, b, eta if gaussian else None))
-            A_all, W_all, b_all, eta_all = self._gather_finish(self._gather_start(packed))
+            packed = torch.from_numpy(self._pack_rows_host(a, W, b, eta if gaussian else None, stats))
+            A_all, W_all, b_all, eta_all, stats_all = self._gather_finish(self._gather_start(packed))
         self._store_rows(0, self.N, A_all, W_all, b_all)
+        self._fresh_stats = stats_all
         if gaussian:
             for n, r in enumerate(self.regressions):
                 r.eta = float(eta_all[n])
@@ -477,6 +536,7 @@ class NonlinearAutoregressiveModel(object):
             self._st = r0._store[:3]
         self._adopt_state()
         self._draws_ahead = None
+        self._fresh_stats = self._stats_kept = None
 
     def plot(self, *args, **kwargs):
         raise NotImplementedError("plotting is outside the scope of the MI355X hot path (SURVEY.md section 2, row 8)")
@@ -505,18 +565,36 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
         self.network = network
 
     def resample_model(self):
+        self._fresh_stats = None
         super(HierarchicalNonlinearAutoregressiveModel, self).resample_model()
-        self.resample_network()
+        stats, self._fresh_stats = self._fresh_stats, None     # the rows' statistics of exactly the state the regressions' sweep just stored
+        self.resample_network(_row_stats=stats)
 
-    def resample_network(self):
+    def _network_stats(self, row_stats):
+        """((n, sum w, sum w w') off the diagonal, the same on it) from the per-row statistics every rank holds after the gather: N rows of
+        1 + B + B^2 doubles added up in neuron order (the same bits whatever the sharding), and the N self-connections read off (A, W)"""
+        A, W, _ = self._adopt_state()
+        B = self.B
+        tot = np.sum(np.asarray(row_stats, dtype=np.float64), axis=0)
+        r = np.arange(self.N)
+        d = A[r, r]
+        Wd = W[r, r, :] * d[:, None]
+        return (tot[0], tot[1:1 + B], tot[1 + B:].reshape(B, B)), (float(d.sum()), Wd.sum(axis=0), Wd.T.dot(Wd))
+
+    def resample_network(self, _row_stats=None):
         """(models.py:228-236).  Every rank holds the full (A, W) after the all_gather and draws the same network
         parameters from an identically seeded host generator; the push evaluates mu_W / sigma_W / rho once
-        instead of once per row."""
+        instead of once per row.  Inside resample_model() the network's sufficient statistics come from the per-row statistics the ranks
+        exchanged with their rows (_row_stats; O(N B^2) on every rank); called on its own -- the state may have been edited since the last
+        sweep -- the network walks (A, W) as the reference does."""
         net = self.network
         state = npr.get_state()
         npr.seed((self.seed * 1000003 + self.sweeps_done) % (2 ** 32))      # identical on every rank
         try:
-            net.resample(self._adopt_state()[:2])         # (the network only reads them)
+            if _row_stats is not None and hasattr(net, "weight_blocks"):
+                net.resample(self._adopt_state()[:2], stats=self._network_stats(_row_stats))
+            else:
+                net.resample(self._adopt_state()[:2])         # (the network only reads them)
         finally:
             npr.set_state(state)
         if hasattr(net, "weight_blocks"):
@@ -541,12 +619,19 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
         n0, n1, N, B = self.n0, self.n1, self.N, self.B
         regs = self.regressions[n0:n1]
         nl = n1 - n0
-        label = np.zeros((nl, N), dtype=np.int64)
+        # (which block a pair takes never changes: the label table is built once per shard, not once per sweep)
+        lkey = (n0, n1, N, S_self is not None)
+        lc = getattr(self, "_label_cache", None)
+        if lc is None or lc[0] != lkey:
+            label = np.zeros((nl, N), dtype=np.int32)
+            if S_self is not None:
+                label[np.arange(nl), np.arange(n0, n1)] = 1
+            lc = self._label_cache = (lkey, label)
+        label = lc[1]
         S_u, mu_u = [S_off], [mu_off]
         if S_self is not None:
             S_u.append(S_self)
             mu_u.append(mu_self)
-            label[np.arange(nl), np.arange(n0, n1)] = 1
         Jw_u, hw_u, _, _, c0_u = prior_terms(np.array(S_u)[None], np.array(mu_u)[None], np.ones(1), np.zeros(1))
         prior = BlockPrior(Jw_u[0], hw_u[0], c0_u[0], label)
         S_b = np.array([r._S_b[0, 0] for r in regs])

@@ -66,6 +66,24 @@ class _NIW(object):
         self.rng = rng                     # None = NumPy's global generator (looked up at use: a module cannot be deep-copied)
         self.resample()
 
+    def resample_stats(self, n, sw, Sww):
+        """the same update from the data's sufficient statistics -- count n, sum sw (D,), sum of outer products Sww (D, D) -- as the ranks
+        of a sharded model exchange them (pgl_row_stats): the scatter about the mean is Sww - n xbar xbar' (one pass; the weights it is used
+        for are centred near 0, so nothing cancels)"""
+        mu_n, sigma_n, kappa_n, nu_n = self.mu_0, self.sigma_0, self.kappa_0, self.nu_0
+        n = float(n)
+        if n > 0:
+            xbar = np.asarray(sw, dtype=float) / n
+            scatter = np.asarray(Sww, dtype=float) - n * np.outer(xbar, xbar)
+            scatter = 0.5 * (scatter + scatter.T)
+            dev = xbar - self.mu_0
+            mu_n = (self.kappa_0 * self.mu_0 + n * xbar) / (self.kappa_0 + n)
+            sigma_n = self.sigma_0 + scatter + self.kappa_0 * n / (self.kappa_0 + n) * np.outer(dev, dev)
+            kappa_n, nu_n = self.kappa_0 + n, self.nu_0 + n
+        rng = np.random if self.rng is None else self.rng
+        self.sigma = _sample_invwishart(sigma_n, nu_n, rng)
+        self.mu = rng.multivariate_normal(mu_n, self.sigma / kappa_n)
+
     def resample(self, data=()):
         D = len(self.mu_0)
         data = np.asarray(data, dtype=float).reshape(-1, D)
@@ -158,9 +176,20 @@ class _IndependentGaussianMixin(_NetworkModel):
     def sigma_W(self):
         return self.sigma_W_rows(0, self.N)
 
-    def resample(self, data=[]):
+    def resample(self, data=[], stats=None):
+        """stats: optional ((n, sum w, sum w w') of the active off-diagonal weight vectors, the same of the active self-connections), as a
+        population model has them from its ranks' rows (models.py: resample_model); the (A, W) walk below is then skipped -- it is O(N^2 B)
+        on every rank of a sharded run.  Same random numbers consumed either way."""
         super(_IndependentGaussianMixin, self).resample(data)
         A, W = data
+        if stats is not None:
+            (n_o, s_o, S_o), (n_d, s_d, S_d) = stats
+            if self.is_diagonal_weight_special:
+                self._gaussian.resample_stats(n_o, s_o, S_o)
+                self._self_gaussian.resample_stats(n_d, s_d, S_d)
+            else:
+                self._gaussian.resample_stats(n_o + n_d, s_o + s_d, S_o + S_d)
+            return
         if self.is_diagonal_weight_special:
             eye = np.eye(self.N, dtype=bool)
             self._gaussian.resample(_take(W, A & ~eye))

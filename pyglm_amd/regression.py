@@ -326,7 +326,7 @@ class _SparsePGRegressionBase(_SparseScalarRegressionBase):
         neuron = 0 if self._store is None else int(self._store[3])
         dev = self._lik_engine_cache[1].dev
         with torch.cuda.device(dev):
-            zd, bd = torch.from_numpy(np.ascontiguousarray(psi)).to(dev), torch.from_numpy(bshape).to(dev)
+            zd, bd = torch.from_numpy(np.array(psi, dtype=np.float64)).to(dev), torch.from_numpy(np.array(bshape)).to(dev)
             out = torch.empty_like(zd)
             call("pgl_pg_draw", ptr(bd), ptr(zd), ptr(out), psi.size, seed, (int(sweep) << 32) | neuron, 0,
                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))

@@ -378,6 +378,32 @@ def test_rccl_group_with_device_id_and_padded_rows_equals_one(tmp_path):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+@pytest.mark.parametrize("N,B,n0,n1", [(37, 3, 8, 29), (70, 32, 0, 70), (130, 1, 64, 130), (5, 8, 4, 5)])
+def test_row_statistics_kernel(N, B, n0, n1):
+    """pgl_row_stats (round 6): [count, sum w, sum w w'] over the active off-diagonal weight vectors of every local row -- the network prior's
+    sufficient statistics (networks.py:132-149) -- against NumPy; a row's numbers are bit-identical whatever shard it is computed in"""
+    import torch
+    from pyglm_amd.engine import GibbsEngine
+    from pyglm_amd.models import host_row_stats
+    rng = np.random.default_rng(N + B)
+    a = rng.random((N, N)) < 0.6
+    a[min(n0 + 1, N - 1), :] = False                    # an empty row
+    W = rng.standard_normal((N, N, B)) * a[:, :, None]
+
+    def stats(lo, hi):
+        eng = GibbsEngine(N, B, lo, hi, batch=min(2, hi - lo))
+        eng.a_dev.copy_(torch.from_numpy(a[lo:hi].astype(np.int32)))
+        eng.W_dev.copy_(torch.from_numpy(W[lo:hi].reshape(hi - lo, -1)))
+        return eng.row_stats().cpu().numpy()
+    got = stats(n0, n1)
+    want = host_row_stats(a[n0:n1], W[n0:n1], n0)
+    np.testing.assert_array_equal(got[:, 0], want[:, 0])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    mid = (n0 + n1) // 2
+    if mid > n0:
+        np.testing.assert_array_equal(np.concatenate([stats(n0, mid), stats(mid, n1)]), got)
+
+
 def test_standalone_regression_cache_is_keyed_by_content():
     """reg.mean(X_train) then reg.mean(X_test) with equal shapes must not return the first result again (the engine cache used to be
     keyed by id(), which CPython reuses for temporaries); data edited in place is uploaded again; equal data is served from the cache"""

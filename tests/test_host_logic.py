@@ -134,6 +134,60 @@ def test_network_prior_shapes_and_niw_update():
     assert abs(tr.mean() - nu_n * B) < 4 * np.sqrt(2 * nu_n * B / len(tr)) and abs(tr.var() / (2 * nu_n * B) - 1) < 0.15
 
 
+def test_network_update_from_row_statistics_equals_the_update_from_the_data():
+    """round 6: inside resample_model() the network prior's NIW updates (networks.py:132-149) take the count / sum / sum of outer products of the
+    active weight vectors from per-row statistics (pgl_row_stats on the device, exchanged with the rows; host_row_stats here) instead of
+    walking the (N, N, B) state on every rank.  Same posterior parameters, same random numbers consumed: the draws agree to rounding with the
+    walk over W[A & ~eye] / W[A & eye] that a direct resample_network() call -- and the reference -- makes."""
+    from pyglm_amd import networks
+    from pyglm_amd.models import SparseBernoulliGLM, host_row_stats
+    from tests._oracle_engine import OracleEngine
+    rng = np.random.default_rng(3)
+    N, B = 12, 3
+    A = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.7 + 0.2
+    st = host_row_stats(A, W, 0)
+    eye = np.eye(N, dtype=bool)
+    data = W[A & ~eye]
+    np.testing.assert_allclose(st[:, 0].sum(), data.shape[0])
+    np.testing.assert_allclose(st[:, 1:1 + B].sum(0), data.sum(0), rtol=1e-13)
+    np.testing.assert_allclose(st[:, 1 + B:].sum(0).reshape(B, B), data.T @ data, rtol=1e-13)
+    np.testing.assert_array_equal(host_row_stats(A[4:9], W[4:9], 4), st[4:9])            # a row's numbers do not depend on the shard
+    g1 = networks._NIW(np.zeros(B), np.eye(B), 1.0, B + 2.0)
+    g2 = networks._NIW(np.zeros(B), np.eye(B), 1.0, B + 2.0)
+    np.random.seed(5)
+    g1.resample(data)
+    np.random.seed(5)
+    g2.resample_stats(data.shape[0], data.sum(0), data.T @ data)
+    np.testing.assert_allclose(g2.mu, g1.mu, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(g2.sigma, g1.sigma, rtol=1e-10, atol=1e-12)
+    np.random.seed(5)
+    g1.resample(np.zeros((0, B)))
+    np.random.seed(5)
+    g2.resample_stats(0, np.zeros(B), np.zeros((B, B)))                                   # no active connection: a draw from the prior
+    np.testing.assert_array_equal(g2.mu, g1.mu)
+    # model level: resample_model() (statistics from the rows) against resample_regressions() + resample_network() (the walk)
+    for special in (True, False):
+        ms = []
+        for k in range(2):
+            np.random.seed(2)
+            m = SparseBernoulliGLM(6, B=2, regression_kwargs=dict(S_w=3.0, mu_b=-1.0), seed=9, engine_factory=OracleEngine)
+            m.network.is_diagonal_weight_special = special
+            np.random.seed(4)
+            m.add_data((np.random.rand(300, 6) < 0.2).astype(float))
+            if k == 0:
+                m.resample_model()
+            else:
+                m.resample_regressions()
+                m.resample_network()
+            ms.append(m)
+        np.testing.assert_array_equal(ms[0].weights, ms[1].weights)
+        for name in ("_gaussian", "_self_gaussian"):
+            np.testing.assert_allclose(getattr(ms[0].network, name).mu, getattr(ms[1].network, name).mu, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(getattr(ms[0].network, name).sigma, getattr(ms[1].network, name).sigma, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(ms[0].regressions[3].S_w, ms[1].regressions[3].S_w, rtol=1e-9)
+
+
 def test_network_constructors_match_the_reference(golden):
     """fixture G12: the NIW hyper-parameters and connection probabilities the REFERENCE's constructors end up with for a set of keyword
     arguments (most never arrive: networks.py:83, 180, 196), for B on both sides of nu_0 >= B; with set_reference_quirks(False) the
