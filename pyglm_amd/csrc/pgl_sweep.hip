@@ -195,7 +195,6 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         // (a partial run -- nrun < nloc -- contracts the Omega and the Kappa columns of its neurons as two pieces)
         const int npieces = nrun < nloc ? 2 : 1;
         const int Mp = nrun < nloc ? r_up(nrun, 2) : 2 * ldn;
-        const long part = (long)2 * ldn * Dp;
         // The number of slices follows from T and D ALONE (up to 64 slices of >= 256 bins; for narrow models as many as any shard's J buffer
         // is sure to hold: ldj^2 / (4 Dp) <= nloc ldj^2 / (2 ldn Dp)), not from how many neurons this shard has: a neuron's sums are then
         // added up in the same order whatever the sharding, and its whole sweep comes out the same to the last bit on 1 GPU or on 8.
@@ -205,34 +204,51 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
         long S = 64;
         if (S > d.Tp / 256) S = d.Tp / 256;
         double* scratch = s->Jbuf;
-        long cap_any = (long)ldj * ldj / (4L * Dp), cap_this = (long)nb * strideJ / part;      // what any shard's buffer holds / what this one's does
+        long cap_any = (long)ldj * ldj / (4L * Dp), scratch_doubles = (long)nb * strideJ;      // slices any shard's buffer holds / doubles this one's has
         if (cap_any < S && (long)kmax * kmax / (4L * Dp) > cap_any) {
             scratch = s->G;
             cap_any = (long)kmax * kmax / (4L * Dp);
-            cap_this = (long)nb * kmax * kmax / part;
+            scratch_doubles = (long)nb * kmax * kmax;
         }
         if (S > cap_any) S = cap_any;
-        if (S > cap_this) S = cap_this;            // (a shard in several batches with a cramped buffer: never at D >= 128)
-        for (int piece = 0; piece < npieces; ++piece) {
-            const double* Ap = d.OK + (long)piece * ldn + nf;            // columns [nf, nf + Mp) of Omega, then of Kappa
-            const long crow = ((long)piece * ldn + nf) * Dp;             // rows of the border: omega sums, then kappa sums
-            if (S >= 2) {
-                const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
-                PglGemmArgs a{};
-                a.A = Ap; a.lda = 2 * ldn; a.strideA = (long)chunk * a.lda; a.a_cols = Mp;
-                a.B = d.X; a.ldb = Dp; a.strideB = (long)chunk * Dp; a.b_cols = Dp;
-                a.C = scratch + crow; a.ldc = Dp; a.strideC = part;
-                a.M = Mp; a.N = (int)D + 1; a.K = chunk; a.nbatch = (int)S; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
-                RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
-                if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
-                    a.A = Ap + (long)S * chunk * a.lda; a.B = d.X + (long)S * chunk * Dp; a.K = rem; a.nbatch = 1; a.beta = 1.0;
-                    RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
-                }
-            } else RC(pgl_contract_tn(Ap, 2 * ldn, Mp, d.X, Dp, Dp, s->border + crow, Dp, Mp, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
-        }
+        // S is now a function of T and D ALONE.  A shard swept in small batches (a user's batch << nloc at small D) may not hold S slices of the
+        // WHOLE border (2 ldn rows) in its scratch: the neurons then go through in column groups of as many as do fit -- never fewer than four
+        // (cap_any) --, each neuron's sums still added in the same slice order (S used to be clamped by this shard's capacity, which
+        // made the last bits depend on the batch size)
         if (S >= 2) {
-            hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, scratch, part, (int)S, s->border, i > 0, Dp, (int)D + 1);
-            PGL_CHECK_LAUNCH();
+            const int chunk = (int)(d.Tp / 16 / S) * 16, rem = d.Tp - (int)S * chunk;
+            long cols_fit = scratch_doubles / (S * Dp) / 2 * 2;                  // border rows (neuron columns of Omega or of Kappa) whose S slices fit
+            const bool whole = npieces == 1 && cols_fit >= 2L * ldn;            // the usual case: [Omega | Kappa] of the whole shard as one product
+            const int cols = nrun < nloc ? r_up(nrun, 2) : ldn;                 // columns of Omega (and of Kappa) to contract
+            const int ngroups_cols = whole ? 2 * ldn : (int)(cols_fit < cols ? cols_fit : cols);
+            for (int piece = 0; piece < (whole ? 1 : 2); ++piece) {
+                const int first = whole ? 0 : nf, count = whole ? 2 * ldn : cols;
+                for (int c0 = 0; c0 < count; c0 += ngroups_cols) {
+                    const int mcols = ngroups_cols < count - c0 ? ngroups_cols : count - c0;
+                    const double* Ap = d.OK + (long)piece * ldn + first + c0;                    // columns of Omega, then of Kappa
+                    const long crow = ((long)piece * ldn + first + c0) * Dp;                     // rows of the border: omega sums, then kappa sums
+                    const long partg = (long)mcols * Dp;
+                    PglGemmArgs a{};
+                    a.A = Ap; a.lda = 2 * ldn; a.strideA = (long)chunk * a.lda; a.a_cols = mcols;
+                    a.B = d.X; a.ldb = Dp; a.strideB = (long)chunk * Dp; a.b_cols = Dp;
+                    a.C = scratch; a.ldc = Dp; a.strideC = partg;
+                    a.M = mcols; a.N = (int)D + 1; a.K = chunk; a.nbatch = (int)S; a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
+                    RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
+                    if (rem > 0) {           // the last rem < 16 S rows: onto the first slice's sums
+                        a.A = Ap + (long)S * chunk * a.lda; a.B = d.X + (long)S * chunk * Dp; a.K = rem; a.nbatch = 1; a.beta = 1.0;
+                        RC(pgl_launch_gemm(PGL_GEMM_PLAIN, a, st));
+                    }
+                    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((partg + 255) / 256)), dim3(256), 0, st, scratch, partg, (int)S, s->border + crow, i > 0, Dp,
+                                       (int)D + 1);
+                    PGL_CHECK_LAUNCH();
+                }
+            }
+        } else {
+            for (int piece = 0; piece < npieces; ++piece) {
+                const double* Ap = d.OK + (long)piece * ldn + nf;            // columns [nf, nf + Mp) of Omega, then of Kappa
+                const long crow = ((long)piece * ldn + nf) * Dp;             // rows of the border: omega sums, then kappa sums
+                RC(pgl_contract_tn(Ap, 2 * ldn, Mp, d.X, Dp, Dp, s->border + crow, Dp, Mp, (int)D + 1, d.Tp, 1.0, i > 0 ? 1.0 : 0.0, st));
+            }
         }
         clk.toc(m);
     }

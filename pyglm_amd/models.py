@@ -588,15 +588,24 @@ class HierarchicalNonlinearAutoregressiveModel(NonlinearAutoregressiveModel):
         exchanged with their rows (_row_stats; O(N B^2) on every rank); called on its own -- the state may have been edited since the last
         sweep -- the network walks (A, W) as the reference does."""
         net = self.network
-        state = npr.get_state()
-        npr.seed((self.seed * 1000003 + self.sweeps_done) % (2 ** 32))      # identical on every rank
-        try:
-            if _row_stats is not None and hasattr(net, "weight_blocks"):
-                net.resample(self._adopt_state()[:2], stats=self._network_stats(_row_stats))
-            else:
-                net.resample(self._adopt_state()[:2])         # (the network only reads them)
-        finally:
-            npr.set_state(state)
+        if hasattr(net, "_set_rng"):
+            # the package's own NIW networks draw from a generator keyed by (seed, sweep) -- identical on every rank, and 20 us to make where
+            # re-seeding NumPy's global Mersenne twister and putting it back costs 110 (a sixth of a sweep at BASELINE configs[0])
+            net._set_rng(np.random.RandomState(np.random.Philox(key=self.seed & (2 ** 64 - 1), counter=[self.sweeps_done, 0, 2, 0])))
+            try:
+                if _row_stats is not None:
+                    net.resample(self._adopt_state()[:2], stats=self._network_stats(_row_stats))
+                else:
+                    net.resample(self._adopt_state()[:2])         # (the network only reads them)
+            finally:
+                net._set_rng(None)
+        else:
+            state = npr.get_state()
+            npr.seed((self.seed * 1000003 + self.sweeps_done) % (2 ** 32))      # a user's network class draws from NumPy's global generator: identical on every rank
+            try:
+                net.resample(self._adopt_state()[:2])
+            finally:
+                npr.set_state(state)
         if hasattr(net, "weight_blocks"):
             # one shared block (+ one for self-connections): pushed as such -- the (N, N, B, B) expansion of sigma_W is 210 MB at N = 1024,
             # a fifth of a second of host time per sweep on every rank, and nothing on the hot path reads it

@@ -9,7 +9,7 @@ update and draw (PARITY UNPINNED against the third-party package, see oracle/pyg
 import warnings
 
 import numpy as np
-import scipy.linalg as sla
+from scipy.linalg.lapack import dtrtrs
 
 from .utils.utils import expand_scalar, expand_cov
 
@@ -48,8 +48,23 @@ def _sample_invwishart(S, nu, rng):
         x = np.diag(np.sqrt(np.atleast_1d(rng.chisquare(nu - np.arange(n)))))
         x[np.triu_indices_from(x, 1)] = rng.randn(n * (n - 1) // 2)
     R = np.linalg.qr(x, "r")
-    T = sla.solve_triangular(R.T, chol.T, lower=True).T
+    # (LAPACK's triangular solve called directly: scipy.linalg.solve_triangular is the same routine behind ~0.3 ms of argument checking,
+    # which at BASELINE configs[0] was a quarter of a sweep)
+    T, info = dtrtrs(np.ascontiguousarray(R.T), np.ascontiguousarray(chol.T), lower=1)
+    if info != 0:
+        raise np.linalg.LinAlgError("inverse-Wishart draw: singular triangular factor")
+    T = T.T
     return T.dot(T.T)
+
+
+def _mvn(rng, mean, cov):
+    """rng.multivariate_normal(mean, cov) of NumPy's legacy generator, restated: standard_normal(d) pushed through the SVD factor of the
+    covariance (numpy/random/mtrand.pyx: x = z . (sqrt(s)[:, None] v) + mean) -- the same numbers from the same stream, without the
+    50 us of argument handling per call"""
+    mean = np.asarray(mean, dtype=float)
+    z = rng.standard_normal(mean.shape[0])
+    _, sv, v = np.linalg.svd(cov)
+    return mean + np.dot(z, np.sqrt(sv)[:, None] * v)
 
 
 def _take(W, mask):
@@ -82,7 +97,7 @@ class _NIW(object):
             kappa_n, nu_n = self.kappa_0 + n, self.nu_0 + n
         rng = np.random if self.rng is None else self.rng
         self.sigma = _sample_invwishart(sigma_n, nu_n, rng)
-        self.mu = rng.multivariate_normal(mu_n, self.sigma / kappa_n)
+        self.mu = _mvn(rng, mu_n, self.sigma / kappa_n)
 
     def resample(self, data=()):
         D = len(self.mu_0)
@@ -104,7 +119,7 @@ class _NIW(object):
             kappa_n, nu_n = self.kappa_0 + n, self.nu_0 + n
         rng = np.random if self.rng is None else self.rng
         self.sigma = _sample_invwishart(sigma_n, nu_n, rng)
-        self.mu = rng.multivariate_normal(mu_n, self.sigma / kappa_n)
+        self.mu = _mvn(rng, mu_n, self.sigma / kappa_n)
 
 
 class _NetworkModel(object):
@@ -155,6 +170,13 @@ class _IndependentGaussianMixin(_NetworkModel):
             r = np.arange(n0, n1)
             out[r - n0, r] = diag
         return out
+
+    def _set_rng(self, rng):
+        """generator the NIW draws take their numbers from (None: NumPy's global one, looked up at use).  A population model hands in one
+        keyed by (seed, sweep) for the duration of a sweep's network update, so that every rank draws the same parameters"""
+        self._gaussian.rng = rng
+        if self.is_diagonal_weight_special:
+            self._self_gaussian.rng = rng
 
     def weight_blocks(self):
         """(mu, Sigma) of an ordinary connection and of a self-connection (None, None if not special): all there is to mu_W / sigma_W"""

@@ -656,6 +656,32 @@ def test_split_border_contraction_two_datasets_nan_scratch(torch_dev, batch):
         np.testing.assert_allclose(W1[n], r.W, rtol=1e-7, atol=1e-9)
 
 
+def test_small_batches_of_a_narrow_model_give_the_bits_of_one_batch(torch_dev):
+    """the number of time slices of the border sums was clamped by what THIS shard's scratch holds (nb ldj^2 doubles), so a shard swept
+    in several small batches (batch << nloc at small D) got other last bits than the same neurons in one batch.  Now the slice count follows
+    from T and D alone and a cramped scratch takes the neurons in column groups: batch = 2, 7 and 100 agree bit for bit (D = 100, T = 20 000:
+    64 slices of the 200 x 112 border are 1.4 M doubles, two neurons' worth of scratch holds 0.5 M)."""
+    from pyglm_amd.engine import make_draws
+    N, B, T = 100, 1, 20000
+    basis, X, Y, rng = _random_problem(N, B, T, seed=3)
+    kw = dict(rho=0.5, S_w=3.0, mu_w=0.0, mu_b=-1.0, S_b=1.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * a[:, :, None]
+    b = rng.standard_normal(N)
+    hyp = _hyp([orc.Regression(N, B, **kw) for _ in range(N)])
+    perm, u, z = make_draws(4, 1, range(N), N, N * B)
+    outs = []
+    for batch in (100, 2, 7):
+        eng = _engine(N, B, batch=batch, gram="fp64")
+        eng.add_data(Y, X=X)
+        outs.append(eng.sweep(a, W, b, *hyp, perm, u, z, seed=4, sweep=1))
+        border = eng.border.cpu().numpy().copy()
+        outs[-1] = outs[-1] + (border,)
+    for o in outs[1:]:
+        for x, y in zip(o, outs[0]):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("gram", ["fp64", "int8"])
 def test_prefix_run_equals_the_same_neurons_of_a_full_sweep(torch_dev, gram):
     """engine.sweep(nrun=k) -- what bench.py's scaling_proxy times: one rank's share of a larger job -- sweeps the first k local neurons
