@@ -311,8 +311,9 @@ def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8)):
     from pyglm_amd.models import shard_bounds
     inputs = model._sweep_inputs()
     state = model.get_state()
+    stats = eng.row_stats().cpu().numpy()          # (the device state is the model's state: the last sweep left it there)
     t0 = time.perf_counter()
-    model.resample_network()
+    model.resample_network(_row_stats=stats)       # as inside resample_model(): from the per-row statistics every rank holds after the gather
     t_net = time.perf_counter() - t0
     model.set_state(state)
     del state
@@ -423,6 +424,10 @@ def main():
         # imported yet) and never will: it only waits for the ranks and passes rank 0's JSON line through.
         sys.exit(self_launch(args.gpus))
 
+    # stdout carries ONE line, the JSON record: libraries that print there (RCCL's version banner at the first collective) go to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -745,7 +750,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, cfg)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

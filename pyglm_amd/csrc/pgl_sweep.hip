@@ -172,7 +172,14 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
     for (int i = 0; i < s->ndatasets; ++i) {
         const pgl_dataset_t& d = s->datasets[i];
         auto m = clk.tic(ST_ACT, 2.0 * d.T * D * nrun);
-        RC(pgl_activation(d.Xt, d.Tp, s->Wt + nf, ldn, d.Psi + nf, ldn, d.T, Dp, nrun, st));
+        {   // Psi[t][n] = sum_d Xt[d][t] Wt[d][n] for the neurons [nf, nf + nrun)  (pgl_activation, with the operand's column count taken from nf on)
+            PglGemmArgs q{};
+            q.A = d.Xt; q.lda = d.Tp; q.a_cols = d.Tp;
+            q.B = s->Wt + nf; q.ldb = ldn; q.b_cols = ldn - nf;
+            q.C = d.Psi + nf; q.ldc = ldn;
+            q.M = d.T; q.N = nrun; q.K = Dp; q.nbatch = 1; q.alpha = 1.0; q.beta = 0.0; q.tri = 0;
+            RC(pgl_launch_gemm(PGL_GEMM_PLAIN, q, st));
+        }
         clk.toc(m);
         m = clk.tic(ST_PG, (double)d.T * nrun);
         if (s->obs == 2) RC(pgl_k_gaussian_stats(d.Psi + nf, ldn, s->bias + nf, d.Y + nf, ldn, s->inv_eta + nf, d.OK + nf, 2 * ldn, d.OK + ldn + nf, 2 * ldn, d.llpart,
