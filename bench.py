@@ -311,7 +311,7 @@ def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8)):
     from pyglm_amd.models import shard_bounds
     inputs = model._sweep_inputs()
     state = model.get_state()
-    stats = eng.row_stats().cpu().numpy()          # (the device state is the model's state: the last sweep left it there)
+    stats = eng.row_stats().cpu().numpy()          # (of the state the last sweep left on the device: for the timing any state of this density does)
     t0 = time.perf_counter()
     model.resample_network(_row_stats=stats)       # as inside resample_model(): from the per-row statistics every rank holds after the gather
     t_net = time.perf_counter() - t0

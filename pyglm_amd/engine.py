@@ -299,6 +299,7 @@ class GibbsEngine(object):
         if self._din is not None:
             new[:sb].copy_(self._din[:sb])
         self._din = new
+        self._stats_dev = None
         self._hin = torch.zeros(cap, dtype=torch.uint8).pin_memory()
         self._hin_np = self._hin.numpy()
         if self._hout is None:
@@ -608,7 +609,7 @@ class GibbsEngine(object):
     # ------------------------------------------------------------------ one Gibbs sweep of the shard's regressions
     @_on_device
     def sweep(self, a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, seed, sweep, omega_override=None, host_overlap=None, nrun=0,
-              after_queue=None, readback=True, nfirst=0, copy=True):
+              after_queue=None, readback=True, nfirst=0, copy=True, want_stats=False):
         """regression.py:265-280 for every local neuron, as ONE call of pgl_sweep (include/pyglm_hip.h): the whole sweep is queued on the
         stream without a host synchronisation.  a (nloc,N) bool, W (nloc,N,B), b (nloc,), hyper-parameters in natural form
         (prior_terms), random inputs from make_draws.  Returns (a, W, b, ll_before) as host arrays.
@@ -621,6 +622,8 @@ class GibbsEngine(object):
         population model packs the new rows (packed_state) and starts its all_gather there, behind the sweep on the same stream.
         readback=False: the new (a, W, b) stay on the device (a_dev / W_dev / b_dev, packed_state); only ll and the status flags come
         back: returns (None, None, None, ll).
+        want_stats: the rows' sufficient statistics for the network prior (row_stats) are taken behind the sweep and come back with the
+        state in the same wait: self.last_row_stats (nloc, 1 + B + B^2), a view of a pinned buffer valid until the next sweep.
         copy=False: the returned a (int32), W, b are VIEWS of the engine's pinned read-back buffer, valid until its next sweep -- for a
         caller that stores them into arrays of its own right away (the population model: one pass over 42 MB at N = 1024 instead of three)."""
         nloc, N, B, D = self.nloc, self.N, self.B, self.D
@@ -709,6 +712,13 @@ class GibbsEngine(object):
         t_launch = time.perf_counter()
         call("pgl_sweep", ctypes.byref(sw), int(seed), int(sweep), st)
         self.launch_seconds += time.perf_counter() - t_launch
+        self.last_row_stats = None
+        if want_stats:
+            if getattr(self, "_stats_dev", None) is None:
+                self._stats_dev = torch.empty((nloc, 1 + B + B * B), dtype=F64, device=self.dev)
+                self._stats_host = torch.empty((nloc, 1 + B + B * B), dtype=F64).pin_memory()
+            call("pgl_row_stats", ptr(self.a_dev), ptr(self.W_dev), ptr(self._stats_dev), N, B, nloc, self.n0, st)
+            self._stats_host.copy_(self._stats_dev, non_blocking=True)        # (pgl_get_state below waits for the stream)
         if after_queue is not None:
             after_queue(self)
         if host_overlap is not None:
@@ -729,6 +739,8 @@ class GibbsEngine(object):
             W_new, b_new = W_new.copy(), b_new.copy()
         ll = hout[off_ll:off_ll + 8 * nloc].view(np.float64).copy()
         status = hout[off_st:off_st + 4 * nloc].view(np.int32).copy()
+        if want_stats:
+            self.last_row_stats = self._stats_host.numpy()
         del keep
         if status.any():
             # the reference's np.linalg.cholesky raises at the first such neuron (regression.py:369-370), with the neurons before it already

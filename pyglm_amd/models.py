@@ -453,8 +453,11 @@ class NonlinearAutoregressiveModel(object):
         if exchange and not gaussian and hasattr(self.engine, "packed_state"):
             # the shard's new rows never visit the host on their own: packed from the sweep's device buffers, gathered, read back once
             kw.update(after_queue=lambda eng: handle.append(self._gather_start(eng.packed_state())), readback=False)
+        need_stats = hasattr(getattr(self, "network", None), "weight_blocks")
         if hasattr(self.engine, "_hout_np"):
             kw["copy"] = False             # (the rows are stored into the model's arrays below, before the engine is used again)
+            if need_stats and "readback" not in kw:
+                kw["want_stats"] = True    # (taken behind the sweep, back in the same wait as the state)
         a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done, **kw)
         if handle:
             self.sweeps_done += 1
@@ -475,8 +478,12 @@ class NonlinearAutoregressiveModel(object):
         self.sweeps_done += 1
         # the rows' sufficient statistics for the network prior (networks.py:132-149), from the state the sweep left on the device
         stats = None
-        if hasattr(getattr(self, "network", None), "weight_blocks"):
-            stats = self.engine.row_stats().cpu().numpy() if hasattr(self.engine, "row_stats") else host_row_stats(a, W, self.n0)
+        if need_stats:
+            stats = getattr(self.engine, "last_row_stats", None)
+            if stats is not None:
+                stats = stats.copy()
+            else:
+                stats = self.engine.row_stats().cpu().numpy() if hasattr(self.engine, "row_stats") else host_row_stats(a, W, self.n0)
         if self._shard_override:
             # (only this shard's rows move: the statistics of the others are formed once and kept -- bench.py --neurons, tools)
             keep = getattr(self, "_stats_kept", None)
