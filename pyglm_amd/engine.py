@@ -621,7 +621,8 @@ class GibbsEngine(object):
         after_queue: optional callable(engine) run right after the sweep has been queued, with the engine's device current -- the
         population model packs the new rows (packed_state) and starts its all_gather there, behind the sweep on the same stream.
         readback=False: the new (a, W, b) stay on the device (a_dev / W_dev / b_dev, packed_state); only ll and the status flags come
-        back: returns (None, None, None, ll).
+        back: returns (None, None, None, ll); flags of a non-positive-definite system do not raise here (self.last_status; they travel in
+        the packed rows and the population model raises on every rank).
         want_stats: the rows' sufficient statistics for the network prior (row_stats) are taken behind the sweep and come back with the
         state in the same wait: self.last_row_stats (nloc, 1 + B + B^2), a view of a pinned buffer valid until the next sweep.
         copy=False: the returned a (int32), W, b are VIEWS of the engine's pinned read-back buffer, valid until its next sweep -- for a
@@ -742,7 +743,8 @@ class GibbsEngine(object):
         if want_stats:
             self.last_row_stats = self._stats_host.numpy()
         del keep
-        if status.any():
+        self.last_status = status
+        if status.any() and readback:
             # the reference's np.linalg.cholesky raises at the first such neuron (regression.py:369-370), with the neurons before it already
             # updated.  Here the whole shard has been computed: the exception names every neuron concerned (global indices) and carries the
             # shard's results, of which the rows of the other neurons are good; the caller's state is left as it was before the sweep
@@ -776,6 +778,10 @@ class GibbsEngine(object):
         p = torch.zeros((nl, rb), dtype=torch.uint8, device=self.dev)
         p[:, :ob] = self.W_dev.view(torch.uint8).view(nl, ob)
         p[:, ob:oe] = self.b_dev.view(torch.uint8).view(nl, 8)
+        if self.obs != 2:
+            # the slot of the Gaussian model's noise variance carries the sweep's status flags here (0 = fine): after the gather EVERY rank sees
+            # every neuron's flag and raises the same LinAlgError in the same sweep, instead of one rank leaving the others at a collective
+            p[:, oe:os_] = self.status.to(F64).view(torch.uint8).view(nl, 8)
         p[:, os_:oa] = self.row_stats().view(torch.uint8).view(nl, oa - os_)
         p[:, oa:oa + self.N] = self.a_dev.to(torch.uint8)
         return p

@@ -460,8 +460,16 @@ class NonlinearAutoregressiveModel(object):
                 kw["want_stats"] = True    # (taken behind the sweep, back in the same wait as the state)
         a, W, b, self.last_loglik_local = self.engine.sweep(a, W, b, rho, Jw, hw, Jb, hb, c0, perm, u, z, self.seed, self.sweeps_done, **kw)
         if handle:
+            A_all, W_all, b_all, flags, stats_all = self._gather_finish(handle[0])
+            if np.any(flags != 0):
+                # (the eta slot of a non-Gaussian row carries the sweep's status flags: every rank sees them all and raises the same error,
+                # with its state as it was before the sweep -- regression.py:369-370 raises LinAlgError from np.linalg.cholesky)
+                bad = np.nonzero(flags)[0]
+                err = np.linalg.LinAlgError("posterior system not positive definite for neurons %s (flags %s)"
+                                            % (bad[:8].tolist(), flags[bad[:8]].astype(int).tolist()))
+                err.neurons, err.flags, err.state = bad.tolist(), flags[bad].astype(int).tolist(), None
+                raise err
             self.sweeps_done += 1
-            A_all, W_all, b_all, _, stats_all = self._gather_finish(handle[0])
             self._store_rows(0, self.N, A_all, W_all, b_all)
             self._fresh_stats = stats_all
             return

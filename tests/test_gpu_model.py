@@ -355,6 +355,57 @@ def test_two_processes_on_a_long_recording_equal_one(tmp_path):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)       # (incl. the log-likelihood totals: per-neuron values summed in neuron order)
 
 
+def _bad_prior_worker(rank, world, port, out_path):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import torch.distributed as dist
+    from pyglm_amd.models import SparseBernoulliGLM
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    np.random.seed(0)
+    N, B, T = 9, 2, 800
+    Y = (np.random.rand(T, N) < 0.2).astype(float)
+    model = SparseBernoulliGLM(N, B=B, regression_kwargs=dict(S_w=2.0, mu_b=-1.0), seed=5, device="cuda:0")
+    model.add_data(Y)
+    model.resample_model()
+    before = (model.adjacency, model.weights, model.sweeps_done)
+    S = np.array(model.regressions[7].S_w)
+    S[:] = -1e-6 * np.eye(B)                       # neuron 7 lives on rank 1 (neurons 5..8)
+    model.regressions[7].S_w = S
+    model.regressions[7].a[:] = True
+    A0 = model.adjacency
+    caught = None
+    try:
+        model.resample_model()
+    except np.linalg.LinAlgError as e:
+        caught = list(e.neurons)
+    unchanged = bool(np.array_equal(model.adjacency, A0) and np.array_equal(model.weights, before[1]) and model.sweeps_done == before[2])
+    model.regressions[7].S_w = 2.0
+    model.resample_model()                           # every rank is still in step: the next sweep's collectives match up
+    np.savez(out_path + ".%d.npz" % rank, caught=np.array(caught if caught is not None else [-1]), unchanged=unchanged, W=model.weights,
+             ll=model.log_likelihood())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_non_positive_definite_posterior_raises_on_every_rank(tmp_path):
+    """a posterior that is not positive definite (regression.py:369-370: LinAlgError from np.linalg.cholesky) on a neuron of rank 1: the
+    status flags travel in the gathered rows, so BOTH ranks raise LinAlgError naming neuron 7 in the same sweep, both keep their pre-sweep
+    state, and after the prior is repaired the next sweep runs on both (no rank was left behind at a collective)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "bad")
+    mp.spawn(_bad_prior_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    for r in (r0, r1):
+        assert r["caught"].tolist() == [7] and bool(r["unchanged"])
+        assert np.all(np.isfinite(r["W"]))
+    np.testing.assert_array_equal(r0["W"], r1["W"])
+    assert float(r0["ll"]) == float(r1["ll"])
+
+
 @pytest.mark.timeout(900)
 def test_rccl_group_with_device_id_and_padded_rows_equals_one(tmp_path):
     """the production layout -- one process per GPU, torch.distributed backend "nccl" (= RCCL), the group constructed with `device_id` --
