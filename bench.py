@@ -682,7 +682,7 @@ def main():
             # the Gram went through the integer matrix cores: `planes` int8 residue-plane products per neuron, T D (D+1) operations each
             # (lower triangle, 2 per multiply-add); HIP events around i8_gram_kernel alone on the launch stream (column statistics =
             # gram.stats, conversion = gram.planes, CRT = gram.crt).  With random operand bytes the package power limit holds the bare
-            # MFMA loop to 4.0 POP/s (tools/ubench_i8.hip, profiles/r01_power_limit.md)
+            # MFMA loop to 4.0 POP/s (tools/ubench_i8.hip, profiles/archive/r01_power_limit.md)
             npl = eng.datasets[0].planes
             grp = eng._i8_scratch[2] if eng._i8_scratch else 0
             ach = npl * gi["work"] / (gi["ms"] * 1e-3) * 1e-12

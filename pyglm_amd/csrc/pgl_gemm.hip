@@ -263,7 +263,7 @@ __device__ __forceinline__ void gemm_item(const PglGemmArgs& g, const long w, do
             if constexpr (CINIT && NLD <= 8) {
                 // The read-modify-write products (rank-k updates of the tableau and the Cholesky).  PMC: their MFMA pipe is busy 0.81 of the time --
                 // the two waves of a SIMD take the pipe turn by turn and so reach their k-step boundaries together, where each reads its eight
-                // fragments and only then issues (profiles/r04_update_kernel_pmc.md).  Here the fragments of k-step kk + 1 are read in the MFMA
+                // fragments and only then issues (profiles/archive/r04_update_kernel_pmc.md).  Here the fragments of k-step kk + 1 are read in the MFMA
                 // shadows of k-step kk into a second register set.  That only fits because the ACCUMULATORS LIVE IN AGPRs: the MFMAs are issued as
                 // inline assembly with a register-class constraint (left to itself hipcc keeps the 128 accumulator registers in VGPRs and, with a
                 // second fragment set, spills accumulator tiles inside the K loop).  93 VGPRs + 128 AGPRs of the 256 a wave may have with two

@@ -950,9 +950,9 @@ int pgl_k_i8_gram(const int8_t* PA, long KpA, int ka0, const int8_t* PB, int8_t*
     // per-neuron half of the operand stream: nothing shares them but the co-walking workgroups of the XCD) are then fetched once per plane,
     // while the X strips, which every column block walks again, are shared by all eight XCDs through the memory-side cache.  Same-box A/B at
     // cfg3, ms per launch of 8 neurons: 6 x 6 100.3-100.6 | 8 x 4 101.5-103.7 | 4 x 8 101.1 | 3 x 12 103.5 | 12 x 3 99.2 | 16 x 4 98.9 |
-    // 16 x 3 98.7 | 16 x 2 98.2-98.6 | 16 x 1 98.5-98.9 (profiles/r04_i8_tile_order_ab.txt).  The flat list of a ragged group keeps 6 x 6.
+    // 16 x 3 98.7 | 16 x 2 98.2-98.6 | 16 x 1 98.5-98.9 (profiles/archive/r04_i8_tile_order_ab.txt).  The flat list of a ragged group keeps 6 x 6.
     // (Pacing the eight XCDs' lists to within one to three rounds of each other -- a bounded wait at item boundaries on the other lists'
-    // counters -- changed nothing: 96.9-97.1 ms without, 96.9-98.2 with, profiles/r04_i8_xcd_pacing_ab.txt: they stay together on their own.)
+    // counters -- changed nothing: 96.9-97.1 ms without, 96.9-98.2 with, profiles/archive/r04_i8_xcd_pacing_ab.txt: they stay together on their own.)
     const bool lists = G % 8 == 0;
     static const int sbr_ab = pgl_ab_int("PGL_I8_SBR", 0), sbc_ab = pgl_ab_int("PGL_I8_SBC", 0);
     const int sbr = sbr_ab > 0 ? sbr_ab : (lists ? ntm : SB), sbc = sbc_ab > 0 ? sbc_ab : (lists ? 2 : SB);

@@ -392,7 +392,7 @@ class GibbsEngine(object):
 
     def _i8_pays(self, T, planes=13):
         """gram='auto' below I8_MIN_D columns: the integer path only if a cost model says it wins by 10 %.  Per neuron and time bin, from rates
-        measured on MI355X at T = 50 000 (profiles/r04_small_D_crossover.md): the fp64 kernel takes 2.9e-14 s per multiply-add slot of its
+        measured on MI355X at T = 50 000 (profiles/archive/r04_small_D_crossover.md): the fp64 kernel takes 2.9e-14 s per multiply-add slot of its
         lower 128-tiles; an item of the integer product (one 320-tile of one plane) 1.9e-8 s on its CU, a launch _i8_rounds item-times for
         its group of neurons; the plane conversion 1.95e-13 s per byte.  Measured, ms per sweep int8 / fp64: D = 320 12.8 / 17.7, D = 500
         (padded to 640) 33.6 / 33.7, D = 640 41.5 / 56, D = 650 (padded to 960) 64.3 / 79.6, D = 900 95.2 / 165.6.

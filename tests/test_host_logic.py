@@ -524,7 +524,7 @@ def test_shard_override_sweeps_its_rows_only():
 
 def test_integer_gram_planning_arithmetic():
     """host arithmetic of the integer Gram's plan (no GPU): item-times of a product launch per group size, and the cost model that decides
-    gram='auto' below 1024 columns from the rates measured in profiles/r04_small_D_crossover.md"""
+    gram='auto' below 1024 columns from the rates measured in profiles/archive/r04_small_D_crossover.md"""
     import types
     from pyglm_amd.engine import GibbsEngine
     r = GibbsEngine._i8_rounds
