@@ -308,7 +308,7 @@ def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8)):
     per-sweep gather as far as one rank can time it (gather_cost_one_rank).  projected = 1 / (max over shards + network + gather).
     NOT measured scaling: no second GPU was involved."""
     import torch
-    from pyglm_amd.models import shard_bounds
+    from pyglm_amd.models import shard_bounds, state_row_layout
     inputs = model._sweep_inputs()
     state = model.get_state()
     stats = eng.row_stats().cpu().numpy()          # (of the state the last sweep left on the device: for the timing any state of this density does)
@@ -345,7 +345,7 @@ def scaling_proxy(model, eng, N, B, T, groups=(2, 4, 8)):
     return {"note": "projection, not measured scaling: every shard of a G-rank job swept on THIS GPU from the bench chain's current state (one sweep "
                     "each; the chain is not advanced); projected = 1 / (slowest shard + replicated host-side network prior + the per-sweep gather as one "
                     "rank can time it)",
-            "host_network_prior_ms": t_net * 1e3, "gather": gather, "allgather_payload_bytes": int(N * (8 * N * B + 16 + -(-N // 8) * 8)),
+            "host_network_prior_ms": t_net * 1e3, "gather": gather, "allgather_payload_bytes": int(N * state_row_layout(N, B)[-1]),
             "per_gpu_count": rows}
 
 
@@ -462,7 +462,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM, SparseGaussianGLM
+    from pyglm_amd.models import SparseBernoulliGLM, NegativeBinomialGLM, SparseGaussianGLM, state_row_layout
     N, B, T, L = cfg["N"], cfg["B"], cfg["T"], cfg["L"]
     np.random.seed(0)
     basis, Y = synth(N, B, T, L)
@@ -510,8 +510,8 @@ def main():
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, me)
     collective = {"backend": (dist.get_backend() if use_dist else None), "world": world if use_dist else 1, "devices": ranks_info,
-                  "per_sweep": "one all_gather_into_tensor of the shard's packed rows (W | b | eta | a bytes: %d B per neuron) + none on the data path; "
-                               "log_likelihood(): one fp64 scalar all_reduce" % (8 * N * B + 16 + -(-N // 8) * 8)}
+                  "per_sweep": "one all_gather_into_tensor of the shard's packed rows (W | b | eta or status | row statistics | a bytes: %d B per neuron) + none "
+                               "on the data path; log_likelihood(): one all_reduce of the N per-neuron fp64 values" % state_row_layout(N, B)[-1]}
 
     # (sweeps of a second or more: ~550 event pairs are noise; configs[0] / configs[1] -- 3 / 50 ms per sweep -- keep the dominant kernel's only)
     timed_stages = TIMED_STAGES if float(N) * N * B * T >= 1e11 else TIMED_STAGES_SMALL

@@ -84,7 +84,7 @@ def test_scaling_proxy_times_every_shard():
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     sp = d["scaling_proxy"]
     assert sp["gather"]["available"] and sp["gather"]["backend"] == "nccl" and sp["gather"]["ms"] > 0
-    assert sp["gather"]["payload_bytes"] == sp["allgather_payload_bytes"] == 128 * (8 * 640 + 16 + 128)
+    assert sp["gather"]["payload_bytes"] == sp["allgather_payload_bytes"] == 128 * (8 * 640 + 16 + 8 * (1 + 5 + 25) + 128)
     for row in sp["per_gpu_count"]:
         G = row["gpus"]
         assert len(row["shard_sweep_ms"]) == G and row["neurons_per_rank"] == 128 // G
