@@ -144,4 +144,9 @@ int pgl_k_flip_pivot_chunk(const PglFlipState&, const int*, long, const int*, in
 int pgl_k_flip_kmax(void);
 int pgl_k_flip_window_blocks(int);
 int pgl_k_chol_index(const PglCholState&, hipStream_t);
+// flips + weight draw of a small model (D + 2 <= pgl_k_small_max_rows(), B <= 16) as one launch, one workgroup per neuron (pgl_small.hip)
+bool pgl_k_small_fits(int N, int B);
+int pgl_k_small_max_rows(void);
+int pgl_k_small_tail(const double* J, long ldj, long strideJ, int nb, int N, int B, const int* perm, const double* u, const double* rho, const double* c0,
+                     int* a, const int* skip, const double* z, long ldz, double* W, double* b, int* status, double* logodds, hipStream_t st);
 int pgl_k_chol_sample(const PglCholState&, int, hipStream_t);

@@ -395,6 +395,16 @@ int pgl_sweep(const pgl_sweep_t* s, uint64_t seed, uint64_t sweep, void* hip_str
                                    nbb, N, B, st));
             clk.toc(m);
         }
+        // ---- a small model (a tableau of at most 98 rows): flips and weight draw as ONE launch with the tableau in LDS (pgl_small.hip).  Which
+        // path a model takes follows from N and B alone (and the engine-wide visit_order option), never from the shard or the batch
+        if (s->visit_order && pgl_k_small_fits(N, B)) {
+            auto ms = clk.tic(ST_FLIPS);
+            RC(pgl_k_small_tail(s->Jbuf, ldj, strideJ, nbb, N, B, s->perm + (long)s0 * N, s->u + (long)s0 * N, s->rho + (long)s0 * N, c0 + (long)s0 * N,
+                                s->a + (long)s0 * N, s->skip + s0, s->z + (long)s0 * (D + 1), D + 1, s->W + (long)s0 * D, s->b + s0, s->status + s0,
+                                s->logodds ? s->logodds + (long)s0 * N : nullptr, st));
+            clk.toc(ms);
+            continue;
+        }
         // ---- collapsed flips (regression.py:282-320)
         auto mf = clk.tic(ST_FLIPS);
         if (!s->all_deterministic) {

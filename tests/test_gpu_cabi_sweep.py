@@ -81,7 +81,8 @@ def test_golden_model_sweep_through_the_c_abi_alone(golden, batch, timed):
         call("pgl_stage_times_collect", ctypes.byref(times))
         names = [lib.pgl_stage_name(i).decode() for i in range(_lib.NSTAGES)]
         got = {n: (times.ms[i], times.calls[i]) for i, n in enumerate(names) if times.calls[i]}
-        assert got["gram"][1] == 2 and got["flips"][1] == 2 and got["weights"][1] == 2 and got["activation"][1] == 1      # batches of 3 + 1
+        # batches of 3 + 1; a model this small takes flips + weight draw as ONE launch per batch (pgl_small.hip), timed under "flips"
+        assert got["gram"][1] == 2 and got["flips"][1] == 2 and "weights" not in got and got["activation"][1] == 1
         assert all(ms >= 0.0 for ms, _ in got.values()) and times.pending is None
     # a second sweep continues the chain from the device-resident state, now with the library's own PG draws
     ds[0].omega_override = None
