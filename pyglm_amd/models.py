@@ -5,8 +5,9 @@ looped over in Python (models.py:169-171) but sent through the HIP kernels in ba
 shard by postsynaptic neuron over the ranks of a torch.distributed process group (one process per GPU):
 
     rank r owns neurons [r*N/G, (r+1)*N/G)   -- its Y columns, its rows of (A, W, b); X is replicated.
-    per sweep:  ONE all_gather_into_tensor of the shard's packed rows (W | b | eta | a as bytes), taken from the device buffers the
-                sweep updated and launched behind it on the stream (the network prior needs the full (A, W), models.py:230);
+    per sweep:  ONE all_gather_into_tensor of the shard's packed rows (W | b | eta or status flags | row statistics | a as bytes), taken from
+                the device buffers the sweep updated and launched behind it on the stream (the network prior needs the full (A, W),
+                models.py:230 -- and of W only the rows' sufficient statistics, which travel with them);
                 all_reduce of the N per-neuron fp64 log-likelihoods (own entries, zeros elsewhere) in log_likelihood().
 Random inputs are keyed by (seed, sweep, global neuron), so results do not depend on the number of ranks.
 """
