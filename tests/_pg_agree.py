@@ -2,7 +2,7 @@
 
 Both sides run the same algorithm on the same random words, so they can only part where an accept/reject comparison sits on a knife edge (libm
 vs OCML ulps in exp/log/erfc, or an activation psi that differs in its last bits: the device sums it on the MFMA, NumPy by dgemv -- 72 % of
-the psi of a sweep are not bit-equal).  MEASURED on MI355X in round 6 (tools/probe_pg_mismatch.py -> profiles/r06_pg_mismatch.json):
+the psi of a sweep are not bit-equal).  MEASURED on MI355X in round 6 (tests/probe_pg_mismatch.py -> profiles/r06_pg_mismatch.json):
     same z on both sides:  0 of 3.0e7 draws differ (b = 1, 3, 2.5);   sweep level (device psi vs NumPy psi):  0 of 2.9e6 Bernoulli draws,
     0 of 8.1e5 negative-binomial draws (xi = 3, 2.5 at 1e-12; xi = 0.7, series branch, at 1e-8)
 i.e. a rate below 1e-7 (95 % bound from 0 of 3e7).  Rounds 1-5 allowed 1e-4 .. 5e-3 without having measured; the tests now allow

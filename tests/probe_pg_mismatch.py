@@ -1,7 +1,7 @@
-"""Measures how often the device's PG draw differs from the oracle's on the shared stream (profiles/r06_pg_mismatch.json):
+"""(test infrastructure: imports the oracle, hence under tests/)  Measures how often the device's PG draw differs from the oracle's on the shared stream (profiles/r06_pg_mismatch.json):
 (a) same z on both sides (accept/reject knife edges only); (b) sweep level -- the device draws from ITS activation (MFMA summation order),
-the oracle from NumPy's (dgemv order), so psi differs by ulps as well.  The parity tests' thresholds are 3x these rates.
-Usage (GPU box): python tools/probe_pg_mismatch.py > gpurun_out/pg_mismatch.json"""
+the oracle from NumPy's (dgemv order), so psi differs by ulps as well.  The parity tests allow 2 draws per comparison (tests/_pg_agree.py).
+Usage (GPU box): python tests/probe_pg_mismatch.py > gpurun_out/pg_mismatch.json"""
 import json
 import os
 import sys
