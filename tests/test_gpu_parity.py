@@ -480,6 +480,41 @@ def test_visit_order_and_plain_tableau_agree(torch_dev):
         np.testing.assert_allclose(outs[0][1][n], r.W, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("N,B,rho", [(12, 3, 0.5), (4, 1, 0.5), (19, 5, 0.3), (96, 1, 0.6), (6, 16, 0.5)])
+def test_small_model_tail_in_one_launch_agrees_with_the_general_path(torch_dev, N, B, rho):
+    """round 6: a model whose tableau has at most 98 rows takes flips + weight draw as ONE launch per batch with the tableau in LDS
+    (pgl_small.hip); an engine with visit_order=False keeps the general path (pivot chunks, proposal windows, blocked Cholesky) at the same
+    size.  Two implementations of regression.py:282-340: the same decisions, log-odds to 1e-9, weights to 1e-9 -- and both equal to the oracle."""
+    from pyglm_amd.engine import make_draws
+    T = 1500
+    basis, X, Y, rng = _random_problem(N, B, T, seed=N + B, n_active_true=min(3, N))
+    kw = dict(rho=rho, S_w=0.5, mu_w=0.0, mu_b=-1.5, S_b=2.0)
+    a = rng.random((N, N)) < 0.5
+    W = rng.standard_normal((N, N, B)) * 0.3 * a[:, :, None]
+    b = rng.standard_normal(N) - 1.5
+    regs = [orc.Regression(N, B, **kw) for _ in range(N)]
+    hyp = _hyp(regs)
+    perm, u, z = make_draws(13, 1, range(N), N, N * B)
+    outs, los = [], []
+    for vo in (True, False):
+        eng = _engine(N, B, visit_order=vo, batch=5)
+        eng.add_data(Y, X=X)
+        eng.keep_logodds = True
+        outs.append(eng.sweep(a, W, b, *hyp, perm, u, z, seed=13, sweep=1))
+        los.append(eng.logodds.cpu().numpy())
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-9, atol=1e-11)
+    np.testing.assert_array_equal(np.isnan(los[0]), np.isnan(los[1]))
+    np.testing.assert_allclose(np.nan_to_num(los[0]), np.nan_to_num(los[1]), rtol=1e-10, atol=1e-9)
+    assert (outs[0][0] != a).sum() > 0
+    omegas = eng.datasets[0].OK[:T, :N].cpu().numpy()
+    ref = _oracle_sweep(N, B, X, Y, a, W, b, kw, omegas, perm, u, z)
+    for n, (ao, Wo, bo, trace) in enumerate(ref):
+        np.testing.assert_array_equal(outs[0][0][n], ao)
+        np.testing.assert_allclose(outs[0][1][n], Wo, rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("gram,T", [("fp64", 600), ("int8", 600), ("fp64", 5000)])
 def test_sharded_equals_unsharded(torch_dev, gram, T):
     """neuron sharding is invisible: two engines over [0,5) and [5,11) reproduce one engine over [0,11) bit for bit (with the fp64 Gram -- also
